@@ -1,0 +1,158 @@
+"""The three BASELINE networks (gradient providers for the samplers).
+
+* ``ClassificationDenseNet`` -- reference ``models/dense_nets.py:16-67``
+* ``ClassificationConvNet``  -- reference ``models/conv_nets.py:18-70``
+* ``ResNet`` (googleresnet, depth 6n+2) -- reference ``models/google_resnet.py:11-78``
+
+Layer order, module names and prior scales follow the reference so parameter
+order (= the sampler's segment order) and ``state_dict`` keys match:
+weight scale = std_w / sqrt(fan) with fan = in_features for Linear and
+**in_channels** (not in_channels*k*k) for Conv2d (``conv_nets.py:26-31``);
+bias prior is N(0, std_b) whatever ``loc_b`` (``dense_nets.py:22-23``);
+googleresnet convolutions have no bias and always use ``conv_prior_w``
+(default Normal; ``google_resnet.py:34-43``), BatchNorm affine parameters are
+sampled without a prior.
+"""
+from torch import nn
+
+from .. import prior
+from .base import ClassificationModel, RegressionModel
+from .layers import Conv2d, Linear
+
+__all__ = ("LinearPrior", "Conv2dPrior", "DenseNet", "ClassificationDenseNet",
+           "ClassificationConvNet", "ResNet", "Reshape")
+
+
+def _default_scaling(std, dim):
+    return std / dim ** 0.5
+
+
+def LinearPrior(in_dim, out_dim, prior_w=prior.Normal, loc_w=0., std_w=1.,
+                prior_b=prior.Normal, loc_b=0., std_b=1., scaling_fn=None,
+                weight_prior_params={}, bias_prior_params={}):
+    scaling_fn = scaling_fn or _default_scaling
+    w = prior_w((out_dim, in_dim), loc_w, scaling_fn(std_w, in_dim), **weight_prior_params)
+    b = prior_b((out_dim,), 0., std_b, **bias_prior_params) if prior_b is not None else None
+    return Linear(w, b)
+
+
+def Conv2dPrior(in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1,
+                groups=1, prior_w=prior.Normal, loc_w=0., std_w=1., prior_b=prior.Normal,
+                loc_b=0., std_b=1., scaling_fn=None, weight_prior_params={}, bias_prior_params={}):
+    scaling_fn = scaling_fn or _default_scaling
+    # bias drawn before the weight: keeps the RNG consumption order of conv_nets.py:28-29
+    b = prior_b((out_channels,), 0., std_b, **bias_prior_params) if prior_b is not None else None
+    w = prior_w((out_channels, in_channels // groups, kernel_size, kernel_size), loc_w,
+                scaling_fn(std_w, in_channels), **weight_prior_params)
+    return Conv2d(w, b, stride=stride, padding=padding, dilation=dilation, groups=groups)
+
+
+class Reshape(nn.Module):
+    def __init__(self, *shape):
+        super().__init__()
+        self.shape = shape
+
+    def forward(self, x):
+        return x.view(self.shape)
+
+
+def _dense_stack(in_features, out_features, width, depth, kw):
+    dims = [in_features] + [width] * (depth - 1) + [out_features]
+    layers = []
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        layers.append(LinearPrior(a, b, **kw))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+def _layer_kwargs(prior_w, loc_w, std_w, prior_b, loc_b, std_b, scaling_fn,
+                  weight_prior_params, bias_prior_params):
+    return dict(prior_w=prior_w, loc_w=loc_w, std_w=std_w, prior_b=prior_b, loc_b=loc_b,
+                std_b=std_b, scaling_fn=scaling_fn, weight_prior_params=weight_prior_params,
+                bias_prior_params=bias_prior_params)
+
+
+def DenseNet(in_features, out_features, width, depth=3, noise_std=1.,
+             prior_w=prior.Normal, loc_w=0., std_w=2 ** .5, prior_b=prior.Normal, loc_b=0.,
+             std_b=1., scaling_fn=None, weight_prior_params={}, bias_prior_params={}):
+    kw = _layer_kwargs(prior_w, loc_w, std_w, prior_b, loc_b, std_b, scaling_fn,
+                       weight_prior_params, bias_prior_params)
+    return RegressionModel(_dense_stack(in_features, out_features, width, depth, kw), noise_std)
+
+
+def ClassificationDenseNet(in_features, out_features, width, depth=3, softmax_temp=1.,
+                           prior_w=prior.Normal, loc_w=0., std_w=2 ** .5, prior_b=prior.Normal,
+                           loc_b=0., std_b=1., scaling_fn=None, weight_prior_params={},
+                           bias_prior_params={}):
+    kw = _layer_kwargs(prior_w, loc_w, std_w, prior_b, loc_b, std_b, scaling_fn,
+                       weight_prior_params, bias_prior_params)
+    return ClassificationModel(_dense_stack(in_features, out_features, width, depth, kw),
+                               softmax_temp)
+
+
+def ClassificationConvNet(in_channels, img_height, out_features, width, depth=3, softmax_temp=1.,
+                          prior_w=prior.Normal, loc_w=0., std_w=2 ** .5, prior_b=prior.Normal,
+                          loc_b=0., std_b=1., scaling_fn=None, weight_prior_params={},
+                          bias_prior_params={}):
+    assert depth >= 2, "We can't have less than two layers"
+    kw = _layer_kwargs(prior_w, loc_w, std_w, prior_b, loc_b, std_b, scaling_fn,
+                       weight_prior_params, bias_prior_params)
+    layers = [Reshape(-1, in_channels, img_height, img_height)]
+    cin = in_channels
+    for _ in range(depth - 1):
+        layers += [Conv2dPrior(cin, width, kernel_size=3, padding=1, **kw), nn.ReLU(),
+                   nn.MaxPool2d(2)]
+        cin = width
+    layers.append(nn.Flatten())
+    flat = width * (img_height // 2 ** (depth - 1)) ** 2
+    layers.append(LinearPrior(flat, out_features, **kw))
+    return ClassificationModel(nn.Sequential(*layers), softmax_temp)
+
+
+class BasicBlock(nn.Module):
+    "conv3x3-BN-ReLU-conv3x3-BN plus identity / 1x1-conv-BN shortcut, ReLU after the sum"
+
+    def __init__(self, in_filters, filters, stride, conv_kwargs, batchnorm):
+        super().__init__()
+        self.main = nn.Sequential(
+            Conv2dPrior(in_filters, filters, kernel_size=3, padding=1, stride=stride, **conv_kwargs),
+            batchnorm(filters), nn.ReLU(),
+            Conv2dPrior(filters, filters, kernel_size=3, padding=1, stride=1, **conv_kwargs),
+            batchnorm(filters))
+        if stride == 1:
+            self.shortcut = nn.Identity()
+        else:
+            self.shortcut = nn.Sequential(
+                Conv2dPrior(in_filters, filters, kernel_size=1, padding=0, stride=stride,
+                            **conv_kwargs),
+                batchnorm(filters))
+
+    def forward(self, x):
+        return nn.functional.relu(self.main(x) + self.shortcut(x))
+
+
+def ResNet(softmax_temp=1., depth=20, num_classes=10, prior_w=prior.Normal, loc_w=0.,
+           std_w=2 ** .5, prior_b=prior.Normal, loc_b=0., std_b=1., scaling_fn=None, bn=True,
+           weight_prior_params={}, bias_prior_params={}, conv_prior_w=prior.Normal):
+    if (depth - 2) % 6 != 0:
+        raise ValueError('depth must be 6n+2 (e.g. 20, 32, 44).')
+    conv_kwargs = dict(prior_w=conv_prior_w, loc_w=loc_w, std_w=std_w, prior_b=None,
+                       scaling_fn=scaling_fn, weight_prior_params=weight_prior_params,
+                       bias_prior_params=bias_prior_params)
+    batchnorm = nn.BatchNorm2d if bn else nn.Identity
+    blocks_per_stack, filters = (depth - 2) // 6, 16
+    layers = [Conv2dPrior(3, filters, kernel_size=3, padding=1, stride=1, **conv_kwargs),
+              batchnorm(filters), nn.ReLU()]
+    for stack in range(3):
+        stride = 1 if stack == 0 else 2
+        prev, filters = filters, filters * stride
+        layers.append(BasicBlock(prev, filters, stride, conv_kwargs, batchnorm))
+        layers += [BasicBlock(filters, filters, 1, conv_kwargs, batchnorm)
+                   for _ in range(blocks_per_stack - 1)]
+    layers += [nn.AvgPool2d(8), nn.Flatten(),
+               LinearPrior(filters, num_classes, prior_w=prior_w, loc_w=loc_w, std_w=std_w,
+                           prior_b=prior_b, loc_b=loc_b, std_b=std_b, scaling_fn=scaling_fn,
+                           weight_prior_params=weight_prior_params,
+                           bias_prior_params=bias_prior_params)]
+    return ClassificationModel(nn.Sequential(*layers), softmax_temp=softmax_temp)

@@ -1,0 +1,66 @@
+"""Element-wise location/scale priors used by the BASELINE configs.
+
+Reference: ``bnn_priors/prior/loc_scale.py:21-103`` (Normal :34, Laplace :66,
+Cauchy :70, StudentT :74-77, Improper :93-96).  Closed forms of log p and its
+gradient, which the fused HIP prior hook implements, are in SURVEY.md
+Appendix A and checked in tests/test_priors.py.
+"""
+import torch.distributions as td
+
+from .base import Prior
+
+__all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "Improper", "get_prior",
+           "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T")
+
+FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T = 0, 1, 2, 3
+
+
+class LocScale(Prior):
+    def __init__(self, shape, loc, scale):
+        super().__init__(shape, loc=loc, scale=scale)
+
+
+class Normal(LocScale):
+    _dist = td.Normal
+    fused_kind = FUSED_NORMAL
+
+
+class Laplace(LocScale):
+    _dist = td.Laplace
+    fused_kind = FUSED_LAPLACE
+
+
+class Cauchy(LocScale):
+    _dist = td.Cauchy
+
+
+class StudentT(LocScale):
+    _dist = td.StudentT
+    fused_kind = FUSED_STUDENT_T
+
+    def __init__(self, shape, loc, scale, df=3):
+        Prior.__init__(self, shape, df=df, loc=loc, scale=scale)
+
+
+class Improper(Normal):
+    "samples like a Normal, contributes nothing to the log-density"
+    fused_kind = None
+
+    def log_prob(self):
+        return 0.0
+
+
+_BY_NAME = {"gaussian": Normal, "laplace": Laplace, "student-t": StudentT,
+            "cauchy": Cauchy, "improper": Improper}
+
+
+def get_prior(name):
+    """Name -> class for the priors on the hot path (reference table:
+    prior/mixture.py:17-50; the remaining names are out of scope)."""
+    if isinstance(name, type) and issubclass(name, Prior):
+        return name
+    try:
+        return _BY_NAME[name]
+    except KeyError:
+        raise KeyError(f"prior '{name}' is outside the accelerated path; "
+                       f"available: {sorted(_BY_NAME)}") from None
