@@ -1,0 +1,124 @@
+"""ctypes binding of the C ABI in include/sgmcmc_hip.h (libsgmcmc_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be
+loaded, every sampler constructor raises.  ``import torch`` happens first so the
+library's ``libamdhip64.so.7`` dependency resolves to the HIP runtime torch has
+already mapped (same SONAME) -- one runtime per process, streams and device
+pointers are shared with torch.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+SOURCE = os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")
+
+ABI_VERSION = 1
+CHUNK = 4096
+NSUMS = 6
+F32, F64 = 0, 1
+VERLET, HMC, SGLD = 0, 1, 2
+INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM = 1, 2, 4, 8, 16, 32
+PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T = 0, 1, 2, 3
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
+
+# numpy mirrors of the device-resident tables
+SEGMENT_DTYPE = np.dtype([("theta", "<u8"), ("g", "<u8"), ("M", "<f8"), ("numel", "<i8"),
+                          ("first_chunk", "<i8"), ("noise_base", "<i8"), ("prior_kind", "<i4"),
+                          ("reserved", "<i4"), ("prior_loc", "<f8"), ("prior_scale", "<f8"),
+                          ("prior_df", "<f8")], align=True)
+CHUNK_DTYPE = np.dtype([("seg", "<i4"), ("n_valid", "<i4")], align=True)
+SEG_STATE_FIELDS = ("sum_gg", "sum_gmo", "sum_gmn", "sum_momo", "sum_mnmn", "sum_thg",
+                    "delta_energy", "prev_delta", "est_temperature", "est_config_temp",
+                    "point_energy", "aux")
+assert SEGMENT_DTYPE.itemsize == 80 and CHUNK_DTYPE.itemsize == 8
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("n_seg", ctypes.c_int32), ("n_chunks", ctypes.c_int64),
+                ("segs", ctypes.c_void_p), ("chunks", ctypes.c_void_p),
+                ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("prev_theta", ctypes.c_void_p),
+                ("prev_g", ctypes.c_void_p), ("prev_m", ctypes.c_void_p),
+                ("partials", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("scalars", ctypes.c_void_p)]
+
+
+class StepArgs(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                ("seg_begin", ctypes.c_int32), ("seg_end", ctypes.c_int32),
+                ("chunk_begin", ctypes.c_int64), ("chunk_end", ctypes.c_int64),
+                ("num_data", ctypes.c_double), ("b2h2", ctypes.c_double), ("bh", ctypes.c_double),
+                ("bhn", ctypes.c_double), ("mom_decay", ctypes.c_double),
+                ("grad_v", ctypes.c_double), ("noise_std", ctypes.c_double),
+                ("rmsprop_alpha", ctypes.c_double), ("grad_clamp", ctypes.c_double),
+                ("seed", ctypes.c_uint64), ("draw", ctypes.c_uint64),
+                ("stream", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+EXPORTS = {
+    "sgmcmc_abi_version": (ctypes.c_int, []),
+    "sgmcmc_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "sgmcmc_step": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs), ctypes.c_void_p]),
+    "sgmcmc_sample_momentum": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
+                                              ctypes.c_void_p]),
+    "sgmcmc_restore": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_int, ctypes.c_uint32,
+                                      ctypes.c_void_p]),
+    "sgmcmc_delta_energy": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_int, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_uint32,
+                                           ctypes.c_void_p]),
+    "sgmcmc_segment_sum": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_int, ctypes.c_uint32,
+                                          ctypes.c_void_p]),
+    "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
+                                            ctypes.c_uint32, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsgmcmc_hip.so (built by ``__graft_entry__.build()``); never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                f"(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.sgmcmc_abi_version() != ABI_VERSION:
+            raise HipExtensionMissing(f"ABI mismatch: library {L.sgmcmc_abi_version()} != {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what} failed: hipError {err} ({lib().sgmcmc_error_string(err).decode()})")
+
+
+def build(verbose=False):
+    """hipcc cross-compile for gfx950 (works without a GPU)."""
+    import subprocess
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, SOURCE, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH

@@ -1,0 +1,620 @@
+// sgmcmc_hip.hip -- gfx950 (MI355X / CDNA4) kernels of the SG-MCMC leapfrog engine
+// and the extern "C" entry points declared in include/sgmcmc_hip.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared  (see __graft_entry__.build)
+// -ffp-contract=off: the element-wise update and the noise transform are SPECIFIED
+// operation by operation (DESIGN.md "Arithmetic spec"); every fused multiply-add is an
+// explicit fmaf()/fma(), everything else rounds individually, so theta/m/v are
+// bit-reproducible against the C oracle.
+//
+// Kernel shape (HBM-bound streaming pass, 28 B/element for an ordinary fp32 step):
+//   grid  = one workgroup per arena chunk of SGMCMC_CHUNK = 4096 elements
+//   block = 256 threads = 4 wavefronts of 64; thread t owns items t, t+256, t+512, t+768,
+//           an item being 4 consecutive elements = one 16-byte access per array (fp32),
+//           so each wave instruction moves a contiguous, aligned 1 KiB.
+//   All 16 loads of a thread (4 arrays x 4 items) are issued before the first use.
+//   Noise: one Philox4x32-10 call per item yields its 4 normals in registers (0 B of HBM).
+//   Dots : exact fp64 products, fp64 accumulate per thread -> wave shuffle reduce ->
+//          LDS across the 4 waves in wave order -> one fp64 partial per (chunk, quantity).
+//          A second small kernel sums a segment's partials in a fixed order and applies
+//          the per-segment energy / temperature bookkeeping.  No float atomics anywhere:
+//          results are bitwise run-to-run reproducible and independent of launch timing.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgmcmc_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = SGMCMC_CHUNK / (kThreads * 4);  // 4
+static_assert(kItems * kThreads * 4 == SGMCMC_CHUNK, "chunk geometry");
+
+// ------------------------------------------------------------------ noise
+// Philox4x32-10; counter layout and transforms: DESIGN.md "Noise".
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float spec_logf(float u) {
+  const uint32_t bits = __float_as_uint(u);
+  int e = (int)(bits >> 23) - 126;
+  const float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F000000u);
+  float x;
+  if (m < 0.70710678f) { e -= 1; x = (m + m) - 1.0f; } else { x = m - 1.0f; }
+  const float z = x * x;
+  float p = 7.0376836292E-2f;
+  p = fmaf(p, x, -1.1514610310E-1f);
+  p = fmaf(p, x, 1.1676998740E-1f);
+  p = fmaf(p, x, -1.2420140846E-1f);
+  p = fmaf(p, x, 1.4249322787E-1f);
+  p = fmaf(p, x, -1.6668057665E-1f);
+  p = fmaf(p, x, 2.0000714765E-1f);
+  p = fmaf(p, x, -2.4999993993E-1f);
+  p = fmaf(p, x, 3.3333331174E-1f);
+  float y = (p * x) * z;
+  const float fe = (float)e;
+  y = fmaf(fe, -2.12194440e-4f, y);
+  y = fmaf(z, -0.5f, y);
+  float r = x + y;
+  r = fmaf(fe, 0.693359375f, r);
+  return r;
+}
+
+__device__ __forceinline__ void spec_sincos2pi(uint32_t k23, float& s_out, float& c_out) {
+  const uint32_t odd = 2u * k23 + 1u;
+  const uint32_t q = (odd + (1u << 21)) >> 22;
+  const int32_t ri = (int32_t)odd - (int32_t)(q << 22);
+  const float r = (float)ri * 5.9604644775390625e-08f;
+  const float phi = r * 6.2831855f;
+  const float z = phi * phi;
+  float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float s = fmaf(ps * z, phi, phi);
+  float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float c = fmaf(pc, z * z, fmaf(z, -0.5f, 1.0f));
+  const uint32_t qq = q & 3u;
+  s_out = (qq == 0) ? s : (qq == 1) ? c : (qq == 2) ? -s : -c;
+  c_out = (qq == 0) ? c : (qq == 1) ? -s : (qq == 2) ? -c : s;
+}
+
+__device__ __forceinline__ float spec_uniform(uint32_t x) {
+  return (float)(2u * (x >> 9) + 1u) * 5.9604644775390625e-08f;
+}
+
+__device__ __forceinline__ void spec_normal4(uint64_t seed, uint32_t stream, uint64_t draw,
+                                             uint32_t purpose, uint64_t quad, float (&z)[4]) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), (uint32_t)draw,
+                (purpose << 28) | ((stream & 0xFFFu) << 16) | (uint32_t)((draw >> 32) & 0xFFFFu),
+                (uint32_t)seed, (uint32_t)(seed >> 32), x);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float t = -2.0f * spec_logf(spec_uniform(x[2 * h]));
+    t = t < 0.0f ? 0.0f : t;
+    const float rad = sqrtf(t);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    float s, c;
+    spec_sincos2pi(x[2 * h + 1] >> 9, s, c);
+    z[2 * h] = rad * c;
+    z[2 * h + 1] = rad * s;
+  }
+}
+
+// ------------------------------------------------------------------ helpers
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T> struct Item { T x[4]; };
+
+template <typename T> __device__ __forceinline__ Item<T> load_item(const T* __restrict__ p);
+template <> __device__ __forceinline__ Item<float> load_item<float>(const float* __restrict__ p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return Item<float>{{v.x, v.y, v.z, v.w}};
+}
+template <> __device__ __forceinline__ Item<double> load_item<double>(const double* __restrict__ p) {
+  const double2 a = *reinterpret_cast<const double2*>(p);
+  const double2 b = *reinterpret_cast<const double2*>(p + 2);
+  return Item<double>{{a.x, a.y, b.x, b.y}};
+}
+template <typename T> __device__ __forceinline__ void store_item(T* __restrict__ p, const Item<T>& v);
+template <> __device__ __forceinline__ void store_item<float>(float* __restrict__ p, const Item<float>& v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v.x[0], v.x[1], v.x[2], v.x[3]);
+}
+template <> __device__ __forceinline__ void store_item<double>(double* __restrict__ p, const Item<double>& v) {
+  *reinterpret_cast<double2*>(p) = make_double2(v.x[0], v.x[1]);
+  *reinterpret_cast<double2*>(p + 2) = make_double2(v.x[2], v.x[3]);
+}
+template <typename T>
+__device__ __forceinline__ Item<T> load_guarded(const T* __restrict__ p, int n) {
+  Item<T> r;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) r.x[l] = l < n ? p[l] : T(0);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_guarded(T* __restrict__ p, const Item<T>& v, int n) {
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < n) p[l] = v.x[l];
+}
+
+template <typename T> __device__ __forceinline__ T clamp_grad(T g, T c) {
+  // torch.clamp semantics: NaN stays NaN (inference.py:219-220)
+  return g < -c ? -c : (g > c ? c : g);
+}
+
+// Deterministic block reduction of NS doubles: wave shuffle tree, then the 4 wave
+// results summed in wave order by one thread per quantity.
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __restrict__ out) {
+  __shared__ double sh[kThreads / 64][NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double x = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    acc[k] = x;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sh[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) s += sh[w][threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+struct ChunkCtx {
+  int32_t seg, n_valid;
+  int64_t seg_off, arena_off;
+};
+__device__ __forceinline__ ChunkCtx chunk_ctx(const sgmcmc_layout& L, int64_t chunk) {
+  const sgmcmc_chunk ce = L.chunks[chunk];
+  ChunkCtx c;
+  c.seg = ce.seg;
+  c.n_valid = ce.n_valid;
+  c.seg_off = (chunk - L.segs[ce.seg].first_chunk) * (int64_t)SGMCMC_CHUNK;
+  c.arena_off = chunk * (int64_t)SGMCMC_CHUNK;
+  return c;
+}
+
+// ------------------------------------------------------------------ step kernel
+// One element of one transition.  KIND selects the integrator; see the arithmetic
+// spec in DESIGN.md and the reference lines cited in include/sgmcmc_hip.h.
+template <typename T, int KIND>
+struct Coef {
+  T grad_lr, stepsz, mom_decay, noise_std, alpha, one_m_alpha, clampv;
+  bool has_decay, has_noise, do_clamp, is_final, no_mom;
+};
+
+template <typename T, int KIND>
+__device__ __forceinline__ void update_elem(const Coef<T, KIND>& C, T xi, T gi, T mo, T th, T vv,
+                                            T& mn, T& th_new, T& v_new, double (&acc)[SGMCMC_NSUMS]) {
+  T mt = mo;  // the momentum the kinetic-temperature metric is taken from (sums[3])
+  if (KIND == SGMCMC_VERLET) {
+    mn = xi * C.noise_std;                              // verlet_sgld.py:163
+    mn = fma_t<T>(gi, C.grad_lr, mn);                   // :164-165
+    if (C.has_decay) mn = fma_t<T>(mo, C.mom_decay, mn);  // :166-167
+  } else if (KIND == SGMCMC_HMC) {
+    mn = fma_t<T>(gi, C.grad_lr, mo);                   // hmc.py:64-65
+  } else {
+    if (C.no_mom) { mn = gi * C.grad_lr; mt = mn; }     // sgld.py:134
+    else { mn = mo * C.mom_decay; mn = fma_t<T>(gi, C.grad_lr, mn); }  // sgld.py:131
+    if (C.has_noise) mn = fma_t<T>(xi, C.noise_std, mn);  // sgld.py:142
+  }
+  const double gd = (double)gi, mod = (double)mo, mnd = (double)mn, mtd = (double)mt;
+  acc[0] = fma(gd, gd, acc[0]);
+  acc[1] = fma(gd, mod, acc[1]);
+  acc[2] = fma(gd, mnd, acc[2]);
+  acc[3] = fma(mtd, mtd, acc[3]);
+  acc[4] = fma(mnd, mnd, acc[4]);
+  acc[5] = fma((double)th, gd, acc[5]);
+  th_new = fma_t<T>(mn, C.stepsz, th);                  // verlet_sgld.py:192-193
+  v_new = vv * C.alpha + (C.one_m_alpha * gi) * gi;     // :195-197
+}
+
+template <typename T, int KIND, bool VEC>
+__global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  const int64_t chunk = A.chunk_begin + blockIdx.x;
+  const ChunkCtx cx = chunk_ctx(L, chunk);
+  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+  const double M = sp->M;
+
+  Coef<T, KIND> C;
+  C.grad_lr = (KIND == SGMCMC_SGLD) ? (T)(-A.bhn * M) : (T)(-.5 * A.grad_v * A.bhn * M);
+  C.stepsz = (T)(A.bh * M);
+  C.mom_decay = (T)A.mom_decay;
+  C.noise_std = (T)A.noise_std;
+  C.alpha = (T)A.rmsprop_alpha;
+  C.one_m_alpha = (T)(1 - A.rmsprop_alpha);
+  C.clampv = (T)A.grad_clamp;
+  C.has_decay = A.mom_decay > 0;
+  C.has_noise = A.noise_std > 0;
+  C.do_clamp = A.grad_clamp > 0;
+  C.is_final = (A.flags & SGMCMC_FINAL) != 0;
+  C.no_mom = (A.flags & SGMCMC_NO_MOMENTUM) != 0;
+  const bool save = (A.flags & SGMCMC_SAVE_STATE) != 0;
+  // SGLD's final step modifies nothing (sgld.py:80-85); Verlet/HMC's writes m only.
+  const bool write_m = !C.no_mom && !(KIND == SGMCMC_SGLD && C.is_final);
+  const bool draw_noise = (KIND != SGMCMC_HMC) && C.has_noise && !(KIND == SGMCMC_SGLD && C.is_final);
+
+  const T* __restrict__ gp = (const T*)sp->g + cx.seg_off;
+  T* __restrict__ thp = (T*)sp->theta + cx.seg_off;
+  T* __restrict__ mp = (T*)L.m + cx.arena_off;
+  T* __restrict__ vp = (T*)L.v + cx.arena_off;
+  T* __restrict__ pth = (T*)L.prev_theta + cx.arena_off;
+  T* __restrict__ pg = (T*)L.prev_g + cx.arena_off;
+  T* __restrict__ pm = (T*)L.prev_m + cx.arena_off;
+  const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
+
+  double acc[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
+
+  if (VEC && cx.n_valid == SGMCMC_CHUNK) {
+    // full chunk: issue every load first, then compute
+    Item<T> g[kItems], m[kItems], th[kItems], v[kItems];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int j = (it * kThreads + threadIdx.x) * 4;
+      g[it] = load_item<T>(gp + j);
+      th[it] = load_item<T>(thp + j);
+      if (!C.no_mom) m[it] = load_item<T>(mp + j);
+      else m[it] = Item<T>{{T(0), T(0), T(0), T(0)}};
+      if (!C.is_final) v[it] = load_item<T>(vp + j);
+      else v[it] = Item<T>{{T(0), T(0), T(0), T(0)}};
+    }
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int j = (it * kThreads + threadIdx.x) * 4;
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (draw_noise) spec_normal4(A.seed, A.stream, A.draw, 0u, (noise0 + (uint64_t)j) >> 2, z);
+      Item<T> mn, tn, vn;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        if (C.do_clamp) g[it].x[l] = clamp_grad<T>(g[it].x[l], C.clampv);
+        update_elem<T, KIND>(C, (T)z[l], g[it].x[l], m[it].x[l], th[it].x[l], v[it].x[l], mn.x[l],
+                             tn.x[l], vn.x[l], acc);
+      }
+      if (save) {
+        store_item<T>(pth + j, th[it]);
+        store_item<T>(pg + j, g[it]);
+        if (!C.no_mom) store_item<T>(pm + j, m[it]);
+      }
+      if (write_m) store_item<T>(mp + j, mn);
+      if (!C.is_final) {
+        store_item<T>(thp + j, tn);
+        store_item<T>(vp + j, vn);
+      }
+    }
+  } else {
+    // ragged tail chunk of a segment, or unaligned base pointers: guarded scalar accesses
+    for (int it = 0; it < kItems; ++it) {
+      const int j = (it * kThreads + threadIdx.x) * 4;
+      const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
+      if (n <= 0) break;
+      Item<T> g = load_guarded<T>(gp + j, n), th = load_guarded<T>(thp + j, n);
+      Item<T> m = C.no_mom ? Item<T>{{T(0), T(0), T(0), T(0)}} : load_guarded<T>(mp + j, n);
+      Item<T> v = C.is_final ? Item<T>{{T(0), T(0), T(0), T(0)}} : load_guarded<T>(vp + j, n);
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (draw_noise) spec_normal4(A.seed, A.stream, A.draw, 0u, (noise0 + (uint64_t)j) >> 2, z);
+      Item<T> mn, tn, vn;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        if (l < n) {
+          if (C.do_clamp) g.x[l] = clamp_grad<T>(g.x[l], C.clampv);
+          update_elem<T, KIND>(C, (T)z[l], g.x[l], m.x[l], th.x[l], v.x[l], mn.x[l], tn.x[l],
+                               vn.x[l], acc);
+        }
+      }
+      if (save) {
+        store_guarded<T>(pth + j, th, n);
+        store_guarded<T>(pg + j, g, n);
+        if (!C.no_mom) store_guarded<T>(pm + j, m, n);
+      }
+      if (write_m) store_guarded<T>(mp + j, mn, n);
+      if (!C.is_final) {
+        store_guarded<T>(thp + j, tn, n);
+        store_guarded<T>(vp + j, vn, n);
+      }
+    }
+  }
+  block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_NSUMS);
+}
+
+// ------------------------------------------------------------------ per-segment finalize
+// Sums a segment's chunk partials in a fixed order (thread t takes chunks t, t+256, ...;
+// then a fixed LDS tree) and applies the reference's scalar bookkeeping.
+template <int NS>
+__device__ __forceinline__ void segment_reduce(const double* __restrict__ partials, int64_t first,
+                                               int64_t n, int stride, double (&out)[NS]) {
+  __shared__ double sh[NS][kThreads];
+  double a[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) a[k] = 0.0;
+  for (int64_t c = threadIdx.x; c < n; c += kThreads) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) a[k] += partials[(first + c) * stride + k];
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sh[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int off = kThreads / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = sh[k][0];
+}
+
+__device__ __forceinline__ int64_t seg_chunks(const sgmcmc_segment& s) {
+  return (s.numel + SGMCMC_CHUNK - 1) / SGMCMC_CHUNK;
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  const int seg = A.seg_begin + blockIdx.x;
+  const sgmcmc_segment s = L.segs[seg];
+  double S[SGMCMC_NSUMS];
+  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  if (threadIdx.x != 0) return;
+  sgmcmc_seg_state* st = &L.state[seg];
+#pragma unroll
+  for (int k = 0; k < SGMCMC_NSUMS; ++k) st->sums[k] = S[k];
+  const double d = (double)s.numel, M = s.M;
+  const bool initial = A.flags & SGMCMC_INITIAL, final_ = A.flags & SGMCMC_FINAL;
+  if (A.kind == SGMCMC_VERLET) {
+    const double c_gm = -.5 * A.bhn * M;  // verlet_sgld.py:170
+    if (initial) {
+      const double curv = M * M * (A.num_data * A.num_data) * A.b2h2 / 8;  // :44-47
+      st->delta_energy = -(curv * S[0]);                                    // :172
+    } else {
+      st->delta_energy += st->prev_delta;  // :174
+      st->delta_energy += c_gm * S[1];     // :175
+    }
+    st->prev_delta = c_gm * S[2];  // :176
+    if (A.flags & SGMCMC_CALC_METRICS) {
+      st->est_temperature = (final_ ? S[4] : S[3]) / d;  // :181-187
+      st->est_config_temp = S[5] * (A.num_data / d);     // :189
+    }
+  } else if (A.kind == SGMCMC_HMC) {
+    if (initial) st->delta_energy = -.5 * S[3];  // hmc.py:49-51
+    if (A.flags & SGMCMC_CALC_METRICS) {
+      st->est_temperature = (final_ ? S[4] : S[3]) / d;  // hmc.py:52-53,59,71
+      st->est_config_temp = S[5] * (A.num_data / d);     // hmc.py:61
+    }
+  } else {
+    if (A.flags & SGMCMC_CALC_METRICS) {
+      st->est_temperature = S[3] / d;                 // sgld.py:127-137
+      st->est_config_temp = S[5] * (A.num_data / d);  // sgld.py:146
+    }
+  }
+  // non-finite gradient detector (raise_on_nan, sgld.py:101-104): sum g^2 is finite iff all g are
+  if (!(S[0] - S[0] == 0.0)) L.scalars[1] = 1.0;
+}
+
+// ------------------------------------------------------------------ auxiliary kernels
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sample_momentum_kernel(sgmcmc_layout L, double std_,
+                                                                   double keep, uint64_t seed,
+                                                                   uint32_t stream, uint64_t draw) {
+  const int64_t chunk = blockIdx.x;
+  const ChunkCtx cx = chunk_ctx(L, chunk);
+  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+  T* __restrict__ mp = (T*)L.m + cx.arena_off;
+  const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
+  const T sd = (T)std_, sk = (T)sqrt(keep);
+  for (int it = 0; it < kItems; ++it) {
+    const int j = (it * kThreads + threadIdx.x) * 4;
+    const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
+    if (n <= 0) break;
+    float z[4];
+    spec_normal4(seed, stream, draw, 1u, (noise0 + (uint64_t)j) >> 2, z);
+    Item<T> mo = (keep == 0.0) ? Item<T>{{T(0), T(0), T(0), T(0)}} : load_guarded<T>(mp + j, n);
+    Item<T> mn;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)  // sgld.py:66-69
+      mn.x[l] = (keep == 0.0) ? (T)z[l] * sd : fma_t<T>((T)z[l], sd, mo.x[l] * sk);
+    if (n == 4) store_item<T>(mp + j, mn); else store_guarded<T>(mp + j, mn, n);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void restore_kernel(sgmcmc_layout L, int restore_m) {
+  const int64_t chunk = blockIdx.x;
+  const ChunkCtx cx = chunk_ctx(L, chunk);
+  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+  T* __restrict__ gp = (T*)sp->g + cx.seg_off;
+  T* __restrict__ thp = (T*)sp->theta + cx.seg_off;
+  T* __restrict__ mp = (T*)L.m + cx.arena_off;
+  const T* __restrict__ pth = (const T*)L.prev_theta + cx.arena_off;
+  const T* __restrict__ pg = (const T*)L.prev_g + cx.arena_off;
+  const T* __restrict__ pm = (const T*)L.prev_m + cx.arena_off;
+  for (int it = 0; it < kItems; ++it) {
+    const int j = (it * kThreads + threadIdx.x) * 4;
+    const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
+    if (n <= 0) break;
+    store_guarded<T>(thp + j, load_guarded<T>(pth + j, n), n);  // verlet_sgld.py:64
+    store_guarded<T>(gp + j, load_guarded<T>(pg + j, n), n);    // :65
+    if (restore_m) store_guarded<T>(mp + j, load_guarded<T>(pm + j, n), n);  // :66-69
+  }
+}
+
+// which: 0 = sum v, 1 = m.m, 2 = g.g (clamped like the step kernel sees it)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dot_kernel(sgmcmc_layout L, int which, double clampv) {
+  const int64_t chunk = blockIdx.x;
+  const ChunkCtx cx = chunk_ctx(L, chunk);
+  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+  const T* __restrict__ src = which == 2 ? (const T*)sp->g + cx.seg_off
+                                         : (const T*)(which == 1 ? L.m : L.v) + cx.arena_off;
+  double acc[1] = {0.0};
+  for (int it = 0; it < kItems; ++it) {
+    const int j = (it * kThreads + threadIdx.x) * 4;
+    const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
+    if (n <= 0) break;
+    const Item<T> x = load_guarded<T>(src + j, n);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < n) {
+        T e = x.x[l];
+        if (which == 2 && clampv > 0) e = clamp_grad<T>(e, (T)clampv);
+        acc[0] = which == 0 ? acc[0] + (double)e : fma((double)e, (double)e, acc[0]);
+      }
+    }
+  }
+  block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_NSUMS);
+}
+
+// mode 0: state.aux = segment sum ; mode 1 (Verlet) / 2 (HMC): state.point_energy
+__global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L, int mode,
+                                                                double num_data, double b2h2) {
+  const int seg = blockIdx.x;
+  const sgmcmc_segment s = L.segs[seg];
+  double S[1];
+  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  if (threadIdx.x != 0) return;
+  sgmcmc_seg_state* st = &L.state[seg];
+  if (mode == 0) st->aux = S[0];
+  else if (mode == 1) st->point_energy = (s.M * s.M * (num_data * num_data) * b2h2 / 8) * S[0];
+  else st->point_energy = .5 * S[0];
+}
+
+__global__ void total_energy_kernel(sgmcmc_layout L) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;  // verlet_sgld.py:32-38, same association as the reference's Python loop
+  for (int s = 0; s < L.n_seg; ++s) total += L.state[s].delta_energy + L.state[s].point_energy;
+  L.scalars[0] = total;
+}
+
+__global__ void debug_normals_kernel(float* out, int64_t start, int64_t n, uint64_t seed,
+                                     uint32_t stream, uint64_t draw, uint32_t purpose) {
+  const int64_t q0 = start >> 2;
+  const int64_t nq = ((start + n + 3) >> 2) - q0;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    float z[4];
+    spec_normal4(seed, stream, draw, purpose, (uint64_t)(q0 + q), z);
+    for (int l = 0; l < 4; ++l) {
+      const int64_t i = ((q0 + q) << 2) + l - start;
+      if (i >= 0 && i < n) out[i] = z[l];
+    }
+  }
+}
+
+template <typename T, bool VEC>
+void launch_step_kind(const sgmcmc_layout& L, const sgmcmc_step_args& A, hipStream_t s) {
+  const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
+  switch (A.kind) {
+    case SGMCMC_VERLET: hipLaunchKernelGGL((step_kernel<T, SGMCMC_VERLET, VEC>), grid, block, 0, s, L, A); break;
+    case SGMCMC_HMC: hipLaunchKernelGGL((step_kernel<T, SGMCMC_HMC, VEC>), grid, block, 0, s, L, A); break;
+    default: hipLaunchKernelGGL((step_kernel<T, SGMCMC_SGLD, VEC>), grid, block, 0, s, L, A); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgmcmc_abi_version(void) { return SGMCMC_ABI_VERSION; }
+
+const char* sgmcmc_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+  if (!L || !A || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
+    return (int)hipErrorInvalidValue;
+  if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = !(A->flags & SGMCMC_UNALIGNED);
+  if (L->dtype == SGMCMC_F32) {
+    if (vec) launch_step_kind<float, true>(*L, *A, s); else launch_step_kind<float, false>(*L, *A, s);
+  } else if (L->dtype == SGMCMC_F64) {
+    if (vec) launch_step_kind<double, true>(*L, *A, s); else launch_step_kind<double, false>(*L, *A, s);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(finalize_step_kernel, dim3((unsigned)(A->seg_end - A->seg_begin)),
+                     dim3(kThreads), 0, s, *L, *A);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint64_t seed,
+                           uint32_t stream, uint64_t draw, void* stream_) {
+  if (!L || L->n_chunks <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream_;
+  const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  if (L->dtype == SGMCMC_F32)
+    hipLaunchKernelGGL(sample_momentum_kernel<float>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
+  else
+    hipLaunchKernelGGL(sample_momentum_kernel<double>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_restore(const sgmcmc_layout* L, int restore_momentum, uint32_t flags, void* stream) {
+  (void)flags;
+  if (!L || L->n_chunks <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  if (L->dtype == SGMCMC_F32)
+    hipLaunchKernelGGL(restore_kernel<float>, grid, block, 0, s, *L, restore_momentum);
+  else
+    hipLaunchKernelGGL(restore_kernel<double>, grid, block, 0, s, *L, restore_momentum);
+  return (int)hipGetLastError();
+}
+
+static int launch_dot(const sgmcmc_layout* L, int which, double clampv, hipStream_t s) {
+  const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  if (L->dtype == SGMCMC_F32) hipLaunchKernelGGL(dot_kernel<float>, grid, block, 0, s, *L, which, clampv);
+  else hipLaunchKernelGGL(dot_kernel<double>, grid, block, 0, s, *L, which, clampv);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, double b2h2,
+                        double grad_clamp, uint32_t flags, void* stream) {
+  (void)flags;
+  if (!L || L->n_chunks <= 0 || (kind != SGMCMC_VERLET && kind != SGMCMC_HMC))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  int err = launch_dot(L, kind == SGMCMC_HMC ? 1 : 2, grad_clamp, s);
+  if (err) return err;
+  hipLaunchKernelGGL(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L,
+                     kind == SGMCMC_HMC ? 2 : 1, num_data, b2h2);
+  hipLaunchKernelGGL(total_energy_kernel, dim3(1), dim3(64), 0, s, *L);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* stream) {
+  (void)flags;
+  if (!L || L->n_chunks <= 0 || which < 0 || which > 2) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  int err = launch_dot(L, which, 0.0, s);
+  if (err) return err;
+  hipLaunchKernelGGL(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L, 0, 0.0, 0.0);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
+                         uint64_t draw, uint32_t purpose, void* stream_) {
+  if (!out || n <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(debug_normals_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, out,
+                     start, n, seed, stream, draw, purpose);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+"""Host side of the HIP leapfrog engine: arena, segment/chunk tables, launches.
+
+One ``Engine`` belongs to one optimizer instance.  It owns the optimizer state
+the reference keeps per tensor in ``optimizer.state[p]`` (momentum, square_avg,
+the three roll-back copies; mcmc/sgld.py:63-69,170, mcmc/verlet_sgld.py:72-83)
+as flat arenas tiled into 4096-element chunks, and the device-resident tables
+that let a single kernel launch sweep every parameter tensor of a group
+(include/sgmcmc_hip.h).  Parameters and gradients are *not* moved: the segment
+table carries their base pointers and is refreshed (one small async H2D copy)
+only when a pointer or a preconditioner changed since the previous launch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _hip
+
+_MASK32 = 0xFFFFFFFF
+
+
+def philox4x32_10(ctr, key):
+    "host statement of the generator in csrc/sgmcmc_hip.hip (for the one M-H uniform)"
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _MASK32, p1 & _MASK32, \
+                         ((p0 >> 32) ^ c3 ^ k1) & _MASK32, p0 & _MASK32
+        k0 = (k0 + 0x9E3779B9) & _MASK32
+        k1 = (k1 + 0xBB67AE85) & _MASK32
+    return c0, c1, c2, c3
+
+
+def mh_uniform(seed, stream, draw):
+    "the Metropolis-Hastings uniform: lane 0 of quad 0, purpose 2 (DESIGN.md 'Noise')"
+    ctr = (0, 0, draw & _MASK32, (2 << 28) | ((stream & 0xFFF) << 16) | ((draw >> 32) & 0xFFFF))
+    x0 = philox4x32_10(ctr, (seed & _MASK32, (seed >> 32) & _MASK32))[0]
+    return (2 * (x0 >> 9) + 1) * 2.0 ** -24
+
+
+class Engine:
+    def __init__(self, param_groups, seed=None, chain_id=0):
+        self.lib = _hip.lib()
+        params = [p for g in param_groups for p in g["params"]]
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev, dt = params[0].device, params[0].dtype
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"bnn_priors_amd samplers run on an MI355X only (parameter on '{dev}'); "
+                "there is no CPU path -- use the reference or oracle/ for CPU runs")
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError(f"unsupported parameter dtype {dt}")
+        for p in params:
+            if p.device != dev or p.dtype != dt:
+                raise TypeError("all parameters must share one device and dtype")
+        self.device, self.dtype, self.params = dev, dt, params
+        self.n_seg = len(params)
+        self.index = {id(p): i for i, p in enumerate(params)}
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        self.seed, self.chain_id, self.draw = int(seed) & (2 ** 64 - 1), int(chain_id), 0
+
+        # ---- tables
+        C = _hip.CHUNK
+        seg = np.zeros(self.n_seg, dtype=_hip.SEGMENT_DTYPE)
+        chunk_rows, first, noise = [], 0, 0
+        self.group_ranges = []
+        s = 0
+        for g in param_groups:
+            s0, c0 = s, first
+            for p in g["params"]:
+                n = p.numel()
+                nc = max(1, -(-n // C))
+                seg[s]["numel"], seg[s]["first_chunk"], seg[s]["noise_base"] = n, first, noise
+                seg[s]["M"] = 1.0
+                for c in range(nc):
+                    chunk_rows.append((s, min(C, n - c * C) if n else 0))
+                first += nc
+                noise += -(-n // 4) * 4
+                s += 1
+            self.group_ranges.append((s0, s, c0, first))
+        self.n_chunks = first
+        self.seg_host = seg
+        self._seg_pinned = torch.empty(seg.nbytes, dtype=torch.uint8).pin_memory()
+        self._seg_dev = torch.empty(seg.nbytes, dtype=torch.uint8, device=dev)
+        chunks = np.array(chunk_rows, dtype=_hip.CHUNK_DTYPE)
+        self._chunk_dev = torch.from_numpy(chunks.view(np.uint8).copy()).to(dev)
+        self._seg_dirty = True
+        self._ptr_cache = None
+        self._unaligned = False
+
+        # ---- arenas and scratch
+        total = self.n_chunks * C
+        self.m = torch.zeros(total, dtype=dt, device=dev)
+        self.v = torch.ones(total, dtype=dt, device=dev)
+        self.prev_theta = self.prev_g = self.prev_m = None
+        self.partials = torch.zeros(self.n_chunks * _hip.NSUMS, dtype=torch.float64, device=dev)
+        self.state_dev = torch.zeros(self.n_seg * len(_hip.SEG_STATE_FIELDS), dtype=torch.float64,
+                                     device=dev)
+        self.scalars = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.layout = _hip.Layout()
+        self._fill_layout()
+        self._state_host = None      # cached D2H copy of state_dev
+        self.momentum_ready = False
+        self.metrics_ready = False
+        self.energy_ready = False
+
+    # ------------------------------------------------------------------ views
+    def _view(self, arena, i):
+        p = self.params[i]
+        off = int(self.seg_host[i]["first_chunk"]) * _hip.CHUNK
+        return arena[off:off + p.numel()].view(p.shape)
+
+    def momentum_view(self, i):
+        return self._view(self.m, i)
+
+    def square_avg_view(self, i):
+        return self._view(self.v, i)
+
+    def ensure_prev(self):
+        if self.prev_theta is None:
+            self.prev_theta = torch.zeros_like(self.m)
+            self.prev_g = torch.zeros_like(self.m)
+            self.prev_m = torch.zeros_like(self.m)
+            self._fill_layout()
+
+    def _fill_layout(self):
+        L = self.layout
+        L.dtype = _hip.F32 if self.dtype == torch.float32 else _hip.F64
+        L.n_seg, L.n_chunks = self.n_seg, self.n_chunks
+        L.segs, L.chunks = self._seg_dev.data_ptr(), self._chunk_dev.data_ptr()
+        L.m, L.v = self.m.data_ptr(), self.v.data_ptr()
+        for name in ("prev_theta", "prev_g", "prev_m"):
+            t = getattr(self, name)
+            setattr(L, name, t.data_ptr() if t is not None else self.m.data_ptr())
+        L.partials, L.state, L.scalars = (self.partials.data_ptr(), self.state_dev.data_ptr(),
+                                          self.scalars.data_ptr())
+
+    # ------------------------------------------------------------------ table refresh
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def refresh(self, preconditioners, need_grad=True, raise_on_no_grad=True):
+        """Bring the device segment table up to date with the parameters' current
+        storage, their gradients' storage and the preconditioners."""
+        ptrs = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                if need_grad and raise_on_no_grad:
+                    raise RuntimeError(f"No gradient for parameter with shape {p.shape}")
+                ptrs.append((p.data_ptr(), 0))
+                continue
+            ptrs.append((p.data_ptr(), g.data_ptr()))
+        if ptrs != self._ptr_cache:
+            unaligned = False
+            for i, p in enumerate(self.params):
+                if not p.is_contiguous():
+                    raise RuntimeError("parameters must be contiguous")
+                g = p.grad
+                if g is not None and (not g.is_contiguous() or g.dtype != self.dtype
+                                      or g.device != self.device):
+                    p.grad = g = g.to(device=self.device, dtype=self.dtype).contiguous()
+                    ptrs[i] = (p.data_ptr(), g.data_ptr())
+                th, gp = ptrs[i]
+                unaligned |= bool(th % 16) or bool(gp % 16)
+                self.seg_host[i]["theta"], self.seg_host[i]["g"] = th, gp
+            self._unaligned = unaligned
+            self._ptr_cache = ptrs
+            self._seg_dirty = True
+        M = self.seg_host["M"]
+        for i, m in enumerate(preconditioners):
+            if M[i] != m:
+                M[i] = m
+                self._seg_dirty = True
+        if self._seg_dirty:
+            self._upload_segments()
+
+    def _upload_segments(self):
+        # the pinned staging buffer may still be in flight from the previous upload
+        if self._seg_inflight():
+            self._upload_event.synchronize()
+        self._seg_pinned.numpy()[:] = self.seg_host.view(np.uint8)
+        self._seg_dev.copy_(self._seg_pinned, non_blocking=True)
+        self._upload_event = torch.cuda.Event()
+        self._upload_event.record(torch.cuda.current_stream(self.device))
+        self._seg_dirty = False
+
+    def _seg_inflight(self):
+        ev = getattr(self, "_upload_event", None)
+        return ev is not None and not ev.query()
+
+    def set_priors(self, specs):
+        "specs[i] = None or (kind, loc, scale, df): enable the in-kernel prior gradient"
+        for i, sp in enumerate(specs):
+            row = self.seg_host[i]
+            if sp is None:
+                row["prior_kind"] = _hip.PRIOR_NONE
+            else:
+                row["prior_kind"], row["prior_loc"], row["prior_scale"], row["prior_df"] = sp
+        self._seg_dirty = True
+
+    # ------------------------------------------------------------------ launches
+    def next_draw(self):
+        d = self.draw
+        self.draw += 1
+        return d
+
+    def _touch(self):
+        self._state_host = None
+
+    def step(self, gi, kind, flags, draw, *, num_data, b2h2, bh, bhn, mom_decay, grad_v, noise_std,
+             rmsprop_alpha, grad_clamp=0.0):
+        s0, s1, c0, c1 = self.group_ranges[gi]
+        if flags & _hip.SAVE_STATE:
+            self.ensure_prev()
+        A = _hip.StepArgs(kind=kind, flags=flags | (_hip.UNALIGNED if self._unaligned else 0),
+                          seg_begin=s0, seg_end=s1, chunk_begin=c0, chunk_end=c1,
+                          num_data=num_data, b2h2=b2h2, bh=bh, bhn=bhn, mom_decay=mom_decay,
+                          grad_v=grad_v, noise_std=noise_std, rmsprop_alpha=rmsprop_alpha,
+                          grad_clamp=grad_clamp, seed=self.seed, draw=draw, stream=self.chain_id)
+        _hip.check(self.lib.sgmcmc_step(ctypes.byref(self.layout), ctypes.byref(A), self.stream()),
+                   "sgmcmc_step")
+        self._touch()
+
+    def sample_momentum(self, std, keep, draw):
+        _hip.check(self.lib.sgmcmc_sample_momentum(ctypes.byref(self.layout), std, keep, self.seed,
+                                                   self.chain_id, draw, self.stream()),
+                   "sgmcmc_sample_momentum")
+        self.momentum_ready = True
+
+    def restore(self, restore_momentum):
+        _hip.check(self.lib.sgmcmc_restore(ctypes.byref(self.layout), int(restore_momentum), 0,
+                                           self.stream()), "sgmcmc_restore")
+
+    def delta_energy_total(self, kind, num_data, b2h2, grad_clamp=0.0):
+        _hip.check(self.lib.sgmcmc_delta_energy(ctypes.byref(self.layout), kind, num_data, b2h2,
+                                                grad_clamp, 0, self.stream()), "sgmcmc_delta_energy")
+        self._touch()
+        return self.scalars[0].item()
+
+    def segment_sums(self, which):
+        _hip.check(self.lib.sgmcmc_segment_sum(ctypes.byref(self.layout), which, 0, self.stream()),
+                   "sgmcmc_segment_sum")
+        self._touch()
+        return self.fetch_state()[:, _hip.SEG_STATE_FIELDS.index("aux")].copy()
+
+    def nonfinite_seen(self, reset=True):
+        flag = self.scalars[1].item() != 0.0
+        if flag and reset:
+            self.scalars[1].zero_()
+        return flag
+
+    def fetch_state(self):
+        "[n_seg, 12] float64 host copy of the per-segment scalars (one sync, cached)"
+        if self._state_host is None:
+            self._state_host = self.state_dev.cpu().numpy().reshape(self.n_seg, -1)
+        return self._state_host
+
+    def seg_scalar(self, i, field):
+        return float(self.fetch_state()[i, _hip.SEG_STATE_FIELDS.index(field)])
+
+    def mh_uniform(self):
+        return mh_uniform(self.seed, self.chain_id, self.next_draw())
+
+
+class SegState(dict):
+    """``optimizer.state[p]`` of the HIP samplers.
+
+    Tensors (``momentum_buffer``, ``square_avg``, ``prev_*``) are views into the
+    engine's arenas and ``preconditioner`` is a plain float the caller may
+    assign (testing/test_hmc.py:25-26).  The running scalars ``delta_energy``,
+    ``prev_new_momentum_delta``, ``est_temperature`` and ``est_config_temp`` live
+    on the device; they are fetched (one D2H copy per launch epoch, shared by all
+    tensors) the first time somebody reads them.
+    """
+    _LAZY = {"delta_energy": ("delta_energy", "energy_ready"),
+             "prev_new_momentum_delta": ("prev_delta", "energy_ready"),
+             "est_temperature": ("est_temperature", "metrics_ready"),
+             "est_config_temp": ("est_config_temp", "metrics_ready")}
+
+    def __init__(self, engine, index):
+        super().__init__()
+        self._engine, self._index = engine, index
+
+    def _lazy_available(self, key):
+        return key in self._LAZY and getattr(self._engine, self._LAZY[key][1])
+
+    def __missing__(self, key):
+        if self._lazy_available(key):
+            return self._engine.seg_scalar(self._index, self._LAZY[key][0])
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or self._lazy_available(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default

@@ -1,0 +1,185 @@
+"""SGLD (SGHMC with symplectic-Euler integration) on the HIP engine.
+
+Drop-in for ``bnn_priors.mcmc.SGLD`` (reference: bnn_priors/mcmc/sgld.py:14-179):
+same constructor, ``sample_momentum`` / ``step`` / ``initial_step`` /
+``final_step`` / ``delta_energy`` / ``update_preconditioner``, same
+``param_groups`` keys and ``state[p]`` keys, same exceptions.  The per-tensor
+Python loop with its 6 ATen launches and up to 2 ``.item()`` syncs per tensor is
+replaced by ONE fused kernel launch per parameter group and no sync.
+
+Extensions (keyword-only, defaults keep the reference behaviour):
+``seed`` / ``chain_id`` key the in-kernel Philox noise (default seed: drawn from
+torch's global CPU generator, so ``torch.manual_seed`` makes runs repeatable).
+"""
+import math
+
+import torch
+
+from .. import _hip
+from .engine import Engine, SegState
+
+__all__ = ("SGLD", "dot")
+
+
+def dot(a, b):
+    "(a*b).sum() as a Python float (reference: mcmc/sgld.py:9-11)"
+    return (a.reshape(-1) @ b.reshape(-1)).item()
+
+
+class SGLD(torch.optim.Optimizer):
+    """SGLD with momentum, preconditioning and temperature diagnostics
+    (Wenzel et al. 2020), fused HIP implementation.
+
+    Args: as the reference (mcmc/sgld.py:17-34): params, lr, num_data,
+    momentum=0, temperature=1., rmsprop_alpha=0.99, rmsprop_eps=1e-8,
+    raise_on_no_grad=True, raise_on_nan=False.
+    """
+    _KIND = _hip.SGLD
+
+    def __init__(self, params, lr, num_data, momentum=0, temperature=1.,
+                 rmsprop_alpha=0.99, rmsprop_eps=1e-8, raise_on_no_grad=True,
+                 raise_on_nan=False, *, seed=None, chain_id=0, grad_clamp=0.0):
+        assert lr >= 0 and num_data >= 0 and momentum >= 0 and temperature >= 0
+        defaults = dict(lr=lr, num_data=num_data, momentum=momentum, rmsprop_alpha=rmsprop_alpha,
+                        rmsprop_eps=rmsprop_eps, temperature=temperature)
+        super().__init__(params, defaults)
+        self.raise_on_no_grad = raise_on_no_grad
+        self.raise_on_nan = raise_on_nan
+        self.grad_clamp = float(grad_clamp)
+        self._engine = Engine(self.param_groups, seed=seed, chain_id=chain_id)
+        for i, p in enumerate(self._engine.params):
+            st = self.state[p] = SegState(self._engine, i)
+            st['square_avg'] = self._engine.square_avg_view(i)
+        self.update_preconditioner()
+        self._step_count = 0  # keeps torch.optim.lr_scheduler happy (sgld.py:45)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def engine(self):
+        return self._engine
+
+    def _preconditioners(self):
+        return [self.state[p].setdefault('preconditioner', 1.) for p in self._engine.params]
+
+    def _install_momentum_views(self):
+        for i, p in enumerate(self._engine.params):
+            self.state[p]['momentum_buffer'] = self._engine.momentum_view(i)
+
+    def _run_closure(self, closure):
+        if closure is None:
+            return None
+        with torch.enable_grad():
+            return closure()
+
+    def _adopt_foreign_momentum(self):
+        """tests and users may rebind state['momentum_buffer'] to their own tensor;
+        copy such a tensor into the arena and restore the view."""
+        eng = self._engine
+        for i, p in enumerate(eng.params):
+            st = self.state[p]
+            mb = dict.get(st, 'momentum_buffer')
+            if mb is None:
+                continue
+            view = eng.momentum_view(i)
+            if mb.data_ptr() != view.data_ptr():
+                view.copy_(mb)
+                st['momentum_buffer'] = view
+
+    def _check_nan(self):
+        if self.raise_on_nan and self._engine.nonfinite_seen():
+            raise ValueError("Gradient is not finite")
+
+    def _launch(self, kind, flags, group_scalars):
+        """refresh tables, then one fused launch per parameter group"""
+        eng = self._engine
+        eng.refresh(self._preconditioners(), raise_on_no_grad=self.raise_on_no_grad)
+        if any(p.grad is None for p in eng.params):
+            # raise_on_no_grad=False: the reference skips such tensors (sgld.py:96-100);
+            # the fused sweep cannot, so give them a zero gradient for this launch
+            for p in eng.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            eng.refresh(self._preconditioners())
+        self._adopt_foreign_momentum()
+        draw = eng.next_draw()
+        for gi, group in enumerate(self.param_groups):
+            sc = group_scalars(group)
+            eng.step(gi, kind, flags, draw, grad_clamp=self.grad_clamp, **sc)
+        self._check_nan()
+
+    # ------------------------------------------------------------------ reference API
+    def delta_energy(self, a, b) -> float:
+        return math.inf  # sgld.py:54-55
+
+    @torch.no_grad()
+    def sample_momentum(self, keep=0.0):
+        "m <- sqrt(keep) m + sqrt(T (1-keep)) xi   (sgld.py:57-69)"
+        assert 0 <= keep and keep <= 1.
+        if keep == 1.:
+            return
+        eng = self._engine
+        temps = {g['temperature'] for g in self.param_groups}
+        if len(temps) != 1:
+            raise NotImplementedError("sample_momentum with per-group temperatures")
+        if keep != 0.0:
+            self._adopt_foreign_momentum()
+        eng.sample_momentum(math.sqrt(temps.pop() * (1 - keep)), float(keep), eng.next_draw())
+        self._install_momentum_views()
+
+    def _sgld_scalars(self, g):
+        # sgld.py:114-117
+        g['hn'] = math.sqrt(g['lr'] * g['num_data'])
+        g['h'] = math.sqrt(g['lr'] / g['num_data'])
+        g['noise_std'] = math.sqrt(2 * (1 - g['momentum']) * g['temperature'])
+        return dict(num_data=g['num_data'], b2h2=g['lr'] / g['num_data'], bh=g['h'], bhn=g['hn'],
+                    mom_decay=g['momentum'], grad_v=1.0,
+                    noise_std=g['noise_std'] if g['temperature'] > 0 else 0.0,
+                    rmsprop_alpha=g['rmsprop_alpha'])
+
+    def _sgld_transition(self, closure, calc_metrics, is_final):
+        loss = self._run_closure(closure)
+        moms = {g['momentum'] > 0 for g in self.param_groups}
+        if len(moms) != 1:
+            raise NotImplementedError("mixing momentum == 0 and momentum > 0 groups")
+        has_mom = moms.pop()
+        if has_mom and not self._engine.momentum_ready:
+            raise RuntimeError("No 'momentum_buffer' stored in state. "
+                               "Perhaps you forgot to call `sample_momentum`?")
+        if not has_mom and is_final and calc_metrics:
+            # the reference hits an unbound local here (sgld.py:132-137)
+            raise UnboundLocalError("SGLD(momentum=0).final_step(calc_metrics=True) is undefined "
+                                    "in the reference (mcmc/sgld.py:132-137)")
+        flags = ((_hip.FINAL if is_final else 0) | (_hip.CALC_METRICS if calc_metrics else 0)
+                 | (0 if has_mom else _hip.NO_MOMENTUM))
+        self._launch(_hip.SGLD, flags, self._sgld_scalars)
+        if calc_metrics:
+            self._engine.metrics_ready = True
+        return loss
+
+    @torch.no_grad()
+    def step(self, closure=None, calc_metrics=True, save_state=False):
+        assert save_state is False
+        return self._sgld_transition(closure, calc_metrics, False)
+    initial_step = step
+
+    @torch.no_grad()
+    def final_step(self, closure=None, calc_metrics=True, save_state=False):
+        assert save_state is False
+        return self._sgld_transition(closure, calc_metrics, True)
+
+    @torch.no_grad()
+    def update_preconditioner(self):
+        """M_p = ((mean(v_p)+eps) / min_q(mean(v_q)+eps))^(-1/4)   (sgld.py:156-179).
+        The means come from one fused reduction over the arena (fp64 accumulate)."""
+        eng = self._engine
+        eng.refresh(self._preconditioners(), need_grad=False)
+        sums = eng.segment_sums(0)
+        precond, smallest, i = [], math.inf, 0
+        for group in self.param_groups:
+            for p in group['params']:
+                s = sums[i] / p.numel() + group['rmsprop_eps']
+                precond.append(s)
+                smallest = min(smallest, s)
+                i += 1
+        for p, s in zip(eng.params, precond):
+            self.state[p]['preconditioner'] = (s / smallest) ** (-1 / 4)

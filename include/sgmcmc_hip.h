@@ -1,0 +1,162 @@
+/*
+ * sgmcmc_hip.h -- C ABI of the MI355X (gfx950) SG-MCMC leapfrog engine.
+ *
+ * This is the drop-in boundary underneath the Python optimizer classes
+ * bnn_priors_amd.mcmc.{SGLD,VerletSGLD,HMC}: plain pointers, sizes and PODs,
+ * no torch types.  Every entry point
+ *   - takes device pointers that the caller owns (nothing is allocated here),
+ *   - enqueues its kernels on the given hipStream_t (passed as void*) and
+ *     returns immediately (no host synchronisation inside),
+ *   - returns a hipError_t as int (0 = success).
+ *
+ * The reference has no FFI: its samplers are pure-Python torch.optim.Optimizer
+ * subclasses.  Each entry point therefore cites the reference *method* whose
+ * per-tensor Python loop it replaces (paths under /root/reference/bnn_priors/).
+ *
+ * Data model
+ * ----------
+ * A sampler instance owns an ARENA tiled into CHUNKs of SGMCMC_CHUNK elements.
+ * Parameter tensor ("segment") s occupies ceil(numel_s / SGMCMC_CHUNK)
+ * consecutive chunks starting at first_chunk_s; the optimizer-owned state
+ * arrays m (momentum), v (RMSprop square_avg), prev_theta / prev_g / prev_m
+ * (Metropolis-Hastings roll-back copies) live in the arena at element offset
+ * chunk * SGMCMC_CHUNK.  theta (the nn.Parameter storage) and g (its .grad)
+ * are NOT moved: kernels reach them through the per-segment base pointers, so
+ * autograd can keep allocating gradients wherever it likes.
+ */
+#ifndef SGMCMC_HIP_H
+#define SGMCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGMCMC_ABI_VERSION 1
+#define SGMCMC_CHUNK 4096 /* elements per arena chunk = 256 threads x 4 items x 4 elements */
+#define SGMCMC_NSUMS 6
+
+enum { SGMCMC_F32 = 0, SGMCMC_F64 = 1 };
+enum { SGMCMC_VERLET = 0, SGMCMC_HMC = 1, SGMCMC_SGLD = 2 };
+/* flags of sgmcmc_step_args */
+enum {
+  SGMCMC_INITIAL = 1,      /* first transition after an M-H point (verlet_sgld.py:86, hmc.py:46) */
+  SGMCMC_FINAL = 2,        /* last transition: theta and v are not modified (verlet_sgld.py:119) */
+  SGMCMC_SAVE_STATE = 4,   /* copy theta,g,m to prev_* first (verlet_sgld.py:72-83) */
+  SGMCMC_CALC_METRICS = 8, /* update est_temperature / est_config_temp */
+  SGMCMC_UNALIGNED = 16,   /* some theta/g base pointer is not 16-byte aligned: scalar loads */
+  SGMCMC_NO_MOMENTUM = 32  /* SGLD with momentum == 0: m is neither read nor written */
+};
+/* element-wise priors the step kernel can differentiate in-flight (prior/loc_scale.py) */
+enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
+       SGMCMC_PRIOR_STUDENT_T = 3 };
+
+/* One parameter tensor.  Device-resident array, written by the host. */
+typedef struct {
+  void* theta;          /* base of the parameter storage (dtype of the layout) */
+  void* g;              /* base of its gradient */
+  double M;             /* state['preconditioner'] (sgld.py:47-52) */
+  int64_t numel;
+  int64_t first_chunk;
+  int64_t noise_base;   /* Philox element index of element 0 (multiple of 4) */
+  int32_t prior_kind;   /* SGMCMC_PRIOR_*; NONE = g already holds the full gradient */
+  int32_t reserved;
+  double prior_loc, prior_scale, prior_df;
+} sgmcmc_segment;
+
+typedef struct {
+  int32_t seg;     /* owning segment */
+  int32_t n_valid; /* elements of this chunk inside the segment (1..SGMCMC_CHUNK) */
+} sgmcmc_chunk;
+
+/* Per-segment running scalars, device-resident, fp64.  The host reads this
+ * array back only when a caller asks for a metric or an energy. */
+typedef struct {
+  double sums[SGMCMC_NSUMS]; /* g.g, g.m_old, g.m_new, m_old.m_old, m_new.m_new, theta_old.g */
+  double delta_energy;       /* state['delta_energy']            (verlet_sgld.py:170-175) */
+  double prev_delta;         /* state['prev_new_momentum_delta'] (verlet_sgld.py:176) */
+  double est_temperature;    /* (verlet_sgld.py:178-187) */
+  double est_config_temp;    /* (verlet_sgld.py:189) */
+  double point_energy;       /* last value computed by sgmcmc_delta_energy */
+  double aux;                /* sgmcmc_segment_sum result (e.g. sum of v) */
+} sgmcmc_seg_state;
+
+typedef struct {
+  int32_t dtype; /* SGMCMC_F32 | SGMCMC_F64 */
+  int32_t n_seg;
+  int64_t n_chunks;
+  const sgmcmc_segment* segs; /* device [n_seg] */
+  const sgmcmc_chunk* chunks; /* device [n_chunks] */
+  void* m;                    /* device arenas, n_chunks * SGMCMC_CHUNK elements each */
+  void* v;
+  void* prev_theta;
+  void* prev_g;
+  void* prev_m;
+  double* partials;        /* device [n_chunks][SGMCMC_NSUMS] scratch */
+  sgmcmc_seg_state* state; /* device [n_seg] */
+  double* scalars;         /* device [8] outputs: [0] total delta energy, [1] non-finite flag */
+} sgmcmc_layout;
+
+/* Scalars of one transition of one parameter group, computed by the host in
+ * double exactly as the reference's _update_group_fn does. */
+typedef struct {
+  int32_t kind;  /* SGMCMC_VERLET | SGMCMC_HMC | SGMCMC_SGLD */
+  uint32_t flags;
+  int32_t seg_begin, seg_end;     /* the group's segments [begin, end) */
+  int64_t chunk_begin, chunk_end; /* and their chunks */
+  double num_data;   /* N */
+  double b2h2;       /* lr / N           (verlet_sgld.py:139) */
+  double bh;         /* sqrt(lr / N)     (verlet_sgld.py:140; sgld.py:116 'h') */
+  double bhn;        /* sqrt(lr * N)     (verlet_sgld.py:141; sgld.py:115 'hn') */
+  double mom_decay;  /* verlet_sgld.py:144,98,131 ; SGLD: momentum a */
+  double grad_v;     /* verlet_sgld.py:145,99,132 */
+  double noise_std;  /* verlet_sgld.py:146,100,133 ; sgld.py:117 ; 0 => no draw */
+  double rmsprop_alpha;
+  double grad_clamp; /* > 0: clamp g to +-grad_clamp in flight (inference.py:219-220); 0 = off */
+  uint64_t seed;     /* Philox key */
+  uint64_t draw;     /* sweep counter */
+  uint32_t stream;   /* chain id */
+  uint32_t reserved;
+} sgmcmc_step_args;
+
+int sgmcmc_abi_version(void);
+const char* sgmcmc_error_string(int err);
+
+/* One transition of one parameter group: fused noise + momentum + position +
+ * RMSprop update and the six per-segment dot products, then the per-segment
+ * energy / temperature bookkeeping.
+ * Replaces SGLD._step_internal + _step_fn (mcmc/sgld.py:88-154),
+ * VerletSGLD.initial_step/step/final_step + _step_fn (mcmc/verlet_sgld.py:85-197),
+ * HMC._step_fn (mcmc/hmc.py:41-79). */
+int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream);
+
+/* m <- sqrt(keep)*m + std*xi   (keep == 0: m <- std*xi).
+ * Replaces SGLD.sample_momentum (mcmc/sgld.py:57-69). */
+int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint64_t seed,
+                           uint32_t stream, uint64_t draw, void* stream_);
+
+/* theta,g,m <- prev_theta,prev_g,prev_m.
+ * Replaces the roll-back loop of VerletSGLD.maybe_reject (mcmc/verlet_sgld.py:62-69). */
+int sgmcmc_restore(const sgmcmc_layout* L, int restore_momentum, uint32_t flags, void* stream);
+
+/* scalars[0] <- sum_s (state[s].delta_energy + point_energy_s), in segment order,
+ * point_energy_s = (M^2 N^2 b2h2 / 8) g.g (Verlet) or 0.5 m.m (HMC), from the
+ * CURRENT g / m.  Replaces VerletSGLD.delta_energy's loop + _point_energy
+ * (mcmc/verlet_sgld.py:27-47, mcmc/hmc.py:32-33); the caller adds (U - U_prev) * N. */
+int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, double b2h2,
+                        double grad_clamp, uint32_t flags, void* stream);
+
+/* state[s].aux <- sum of v over segment s (which = 0), of m*m (1) or g*g (2).
+ * which = 0 replaces the square_avg.mean() loop of SGLD.update_preconditioner
+ * (mcmc/sgld.py:156-179); the host finishes (mean + eps, min, ^(-1/4)). */
+int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* stream);
+
+/* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
+int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
+                         uint64_t draw, uint32_t purpose, void* stream_);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMCMC_HIP_H */

@@ -1,0 +1,241 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the goldens.
+
+Bars: bit-exact for integers and flags (Philox words, accept/reject, step indices)
+and -- because the arithmetic is specified operation by operation -- also for the
+element-wise state theta / m / v against the C oracle; fp64-accumulated dot products
+within 1e-12 relative of the oracle's serial fp64 sums (only the summation order
+differs); golden trajectories from the reference within the north star's floating
+point tolerance (written next to each assertion).
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import scenarios as S
+from helpers import PlainHooks, compare, default_dtype, golden
+from oracle import noise
+from oracle.flat import FLAG_FINAL, FLAG_INITIAL, FLAG_SAVE, FlatArena
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mcmc():
+    from bnn_priors_amd import mcmc
+    return mcmc
+
+
+# ------------------------------------------------------------------ noise
+@pytest.mark.parametrize("start,n,seed,stream,draw,purpose", [
+    (0, 1 << 16, 1234, 0, 0, 0), (3, 4099, 2 ** 63 + 5, 7, 2 ** 35 + 1, 1),
+    (2 ** 34 + 6, 1000, 99, 4095, 17, 2), (1, 1, 5, 1, 1, 0)])
+def test_device_normals_bit_exact(start, n, seed, stream, draw, purpose):
+    from bnn_priors_amd import _hip
+    out = torch.empty(n, dtype=torch.float32, device=DEV)
+    _hip.check(_hip.lib().sgmcmc_debug_normals(out.data_ptr(), start, n, seed, stream, draw, purpose,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "debug_normals")
+    ref = noise.normals(seed, stream, draw, purpose, start, n)
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_single_hip_runtime_in_process():
+    _mcmc()
+    from bnn_priors_amd import _hip
+    _hip.lib()
+    libs = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+
+
+# ------------------------------------------------------------------ flat step vs C oracle
+NUMELS = [5, 4096, 1, 4097, 130, 12288, 64]
+
+
+def _setup(kind, dtype, a, T, numels=NUMELS, seed=4242, stream=2):
+    mcmc = _mcmc()
+    g = torch.Generator().manual_seed(11)
+    params = [torch.nn.Parameter(torch.randn(n, generator=g, dtype=torch.float64).to(dtype).to(DEV))
+              for n in numels]
+    if kind == "hmc":
+        opt = mcmc.HMC(params, lr=0.02, num_data=7, raise_on_nan=False, seed=seed, chain_id=stream)
+    else:
+        cls = mcmc.VerletSGLD if kind == "verlet" else mcmc.SGLD
+        opt = cls(params, lr=0.02, num_data=7, momentum=a, temperature=T, seed=seed, chain_id=stream)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    fa = FlatArena(numels, npdt)
+    for s, p in enumerate(params):
+        opt.state[p]['preconditioner'] = 0.3 + 0.1 * s
+        v0 = (torch.rand(p.shape, generator=g, dtype=torch.float64) + 0.5).to(dtype)
+        opt.state[p]['square_avg'].copy_(v0)
+        fa.seg(fa.v, s)[:] = v0.numpy()
+        fa.seg(fa.theta, s)[:] = p.detach().cpu().numpy()
+        fa.M[s] = 0.3 + 0.1 * s
+    return params, opt, fa, g
+
+
+def _set_grads(params, fa, g, dtype, scale=1.0):
+    for s, p in enumerate(params):
+        gr = (scale * torch.randn(p.shape, generator=g, dtype=torch.float64)).to(dtype)
+        p.grad = gr.to(DEV)
+        fa.seg(fa.g, s)[:] = gr.numpy()
+
+
+def _assert_state_bit_exact(params, opt, fa, check_m=True, what=""):
+    for s, p in enumerate(params):
+        assert np.array_equal(p.detach().cpu().numpy(), fa.seg(fa.theta, s)), f"theta seg {s} {what}"
+        assert np.array_equal(opt.state[p]['square_avg'].cpu().numpy(), fa.seg(fa.v, s)), f"v seg {s} {what}"
+        if check_m:
+            assert np.array_equal(opt.state[p]['momentum_buffer'].cpu().numpy(), fa.seg(fa.m, s)), \
+                f"m seg {s} {what}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind,a,T", [("verlet", 0.9, 0.75), ("verlet", 0.0, 1.0), ("verlet", 1.0, 1.0),
+                                      ("verlet", 0.994, 0.0), ("hmc", 1.0, 1.0), ("sgld", 0.9, 0.75),
+                                      ("sgld", 0.0, 0.75), ("sgld", 0.9, 0.0)])
+def test_step_bit_exact_vs_c_oracle(kind, a, T, dtype):
+    params, opt, fa, g = _setup(kind, dtype, a, T)
+    eng = opt.engine
+    opt.sample_momentum()
+    fa.sample_momentum(math.sqrt(T if kind != "hmc" else 1.0), 0.0, 4242, 0, stream=2)
+    _assert_state_bit_exact(params, opt, fa, what="after sample_momentum")
+    calls = [("initial", FLAG_INITIAL | FLAG_SAVE), ("middle", 0), ("middle", 0), ("final", FLAG_FINAL)]
+    for step_i, (which, flags) in enumerate(calls):
+        _set_grads(params, fa, g, dtype)
+        if kind == "sgld":
+            if which == "final":
+                opt.final_step(calc_metrics=a > 0)
+            else:
+                opt.step()
+            grp = opt.param_groups[0]
+            sums = fa.step("sgld", grad_v=1.0, bhn=grp['hn'], bh=grp['h'], mom_decay=a,
+                           noise_std=grp['noise_std'] if T > 0 else 0.0, alpha=0.99, seed=4242,
+                           draw=step_i + 1, stream=2, flags=flags & ~FLAG_SAVE).copy()
+        else:
+            if which == "initial":
+                opt.initial_step(save_state=True)
+            elif which == "middle":
+                opt.step()
+            else:
+                opt.final_step()
+            grp = opt.param_groups[0]
+            sums = fa.step(kind, grad_v=grp['grad_v'], bhn=grp['bhn'], bh=grp['bh'],
+                           mom_decay=grp['mom_decay'], noise_std=grp['noise_std'], alpha=0.99,
+                           seed=4242, draw=step_i + 1, stream=2, flags=flags).copy()
+        _assert_state_bit_exact(params, opt, fa, check_m=not (kind == "sgld" and a == 0),
+                                what=f"after {which} #{step_i}")
+        dev_sums = eng.fetch_state()[:, :6]
+        np.testing.assert_allclose(dev_sums, sums, rtol=1e-12, atol=1e-300)
+        if flags & FLAG_SAVE:
+            for s, p in enumerate(params):
+                st = opt.state[p]
+                assert np.array_equal(st['prev_parameter'].cpu().numpy(), fa.seg(fa.prev_theta, s))
+                assert np.array_equal(st['prev_grad'].cpu().numpy(), fa.seg(fa.prev_g, s))
+                assert np.array_equal(st['prev_momentum_buffer'].cpu().numpy(), fa.seg(fa.prev_m, s))
+    # momentum refresh with keep != 0 (sgld.py:69)
+    if kind != "sgld" or a > 0:
+        opt.sample_momentum(keep=0.3)
+        fa.sample_momentum(math.sqrt((T if kind != "hmc" else 1.0) * 0.7), 0.3, 4242, len(calls) + 1, stream=2)
+        _assert_state_bit_exact(params, opt, fa, what="after partial refresh")
+
+
+def test_unaligned_pointers_take_scalar_path_and_agree():
+    "parameters that are views at odd offsets of a bigger buffer (4-byte aligned only)"
+    mcmc = _mcmc()
+    dtype = torch.float32
+    numels = [4099, 33]
+    gcpu = torch.Generator().manual_seed(5)
+    buf = torch.randn(sum(numels) + 8, generator=gcpu).to(DEV)
+    gbuf = torch.randn(sum(numels) + 8, generator=gcpu).to(DEV)
+    params, off = [], 1
+    for n in numels:
+        p = torch.nn.Parameter(torch.empty(0, device=DEV))
+        p.data = buf[off:off + n]
+        p.grad = gbuf[off:off + n]
+        params.append(p)
+        off += n + 2
+    assert any(p.data_ptr() % 16 for p in params)
+    opt = mcmc.VerletSGLD(params, lr=0.02, num_data=7, momentum=0.9, temperature=1.0, seed=1, chain_id=0)
+    fa = FlatArena(numels, np.float32)
+    for s, p in enumerate(params):
+        fa.seg(fa.theta, s)[:] = p.detach().cpu().numpy()
+        fa.seg(fa.g, s)[:] = p.grad.cpu().numpy()
+        fa.seg(fa.v, s)[:] = 1.0
+    opt.sample_momentum()
+    fa.sample_momentum(1.0, 0.0, 1, 0)
+    opt.initial_step(save_state=False)
+    assert opt.engine._unaligned
+    grp = opt.param_groups[0]
+    fa.step("verlet", grad_v=grp['grad_v'], bhn=grp['bhn'], bh=grp['bh'], mom_decay=grp['mom_decay'],
+            noise_std=grp['noise_std'], alpha=0.99, seed=1, draw=1, flags=FLAG_INITIAL)
+    _assert_state_bit_exact(params, opt, fa)
+
+
+def test_gradient_clamp_in_flight():
+    "grad_clamp reproduces p.grad.clamp_(+-c) before the step (inference.py:219-220)"
+    params, opt, fa, g = _setup("verlet", torch.float32, 0.9, 1.0)
+    opt.grad_clamp = 0.5
+    opt.sample_momentum()
+    fa.sample_momentum(1.0, 0.0, 4242, 0, stream=2)
+    _set_grads(params, fa, g, torch.float32, scale=1.0)
+    np.clip(fa.g, -0.5, 0.5, out=fa.g)
+    opt.initial_step(save_state=True)
+    grp = opt.param_groups[0]
+    sums = fa.step("verlet", grad_v=grp['grad_v'], bhn=grp['bhn'], bh=grp['bh'],
+                   mom_decay=grp['mom_decay'], noise_std=grp['noise_std'], alpha=0.99, seed=4242,
+                   draw=1, stream=2, flags=FLAG_INITIAL | FLAG_SAVE).copy()
+    _assert_state_bit_exact(params, opt, fa)
+    np.testing.assert_allclose(opt.engine.fetch_state()[:, :6], sums, rtol=1e-12)
+    for s, p in enumerate(params):
+        assert np.array_equal(opt.state[p]['prev_grad'].cpu().numpy(), fa.seg(fa.prev_g, s))
+
+
+def test_determinism_same_seed_same_bits():
+    outs = []
+    for _ in range(2):
+        params, opt, fa, g = _setup("verlet", torch.float32, 0.9, 1.0, numels=[100000, 37, 8192])
+        opt.sample_momentum()
+        for k in range(5):
+            _set_grads(params, fa, g, torch.float32)
+            (opt.initial_step if k == 0 else opt.step)()
+        de = opt.delta_energy(0.0, 0.0)
+        outs.append((torch.cat([p.detach().reshape(-1) for p in params]).cpu().numpy().copy(),
+                     opt.engine.fetch_state().copy(), de))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+    assert outs[0][2] == outs[1][2]
+
+
+# ------------------------------------------------------------------ goldens from the reference
+def run_hip(name, dtype_name):
+    import bnn_priors_amd.models as models
+    mcmc = _mcmc()
+    cfg = S.SCENARIOS[name]
+    dtype = getattr(torch, dtype_name)
+    with default_dtype(dtype):
+        torch.manual_seed(0)
+        model, closure = S.make_model(cfg["model"], models, dtype, device=DEV)
+        classes = dict(sgld=mcmc.SGLD, verlet=mcmc.VerletSGLD, hmc=mcmc.HMC)
+        opt = S.build_optimizer(classes, model.parameters(), cfg, seed=S.SEED, chain_id=0)
+        S.preset(model, opt, cfg, dtype, lambda p: opt.state[p])
+        return S.drive(opt, model, closure, cfg, PlainHooks(opt))
+
+
+@pytest.mark.parametrize("dtype_name", S.DTYPES)
+@pytest.mark.parametrize("name", sorted(S.SCENARIOS))
+def test_hip_reproduces_reference_goldens(name, dtype_name):
+    """Same Philox key as the golden run of the imported reference.  Accept/reject
+    flags, M-H step indices and the LR stream must be identical; floats: the
+    gradients come from device autograd (different libm / reduction order than the
+    CPU), so trajectories agree to ~1e-6 relative per step in fp32 and ~1e-13 in fp64;
+    tolerances below leave room for 24 steps of growth."""
+    rec = run_hip(name, dtype_name)
+    if dtype_name == "float32":
+        big = "biglr" in name  # lr = 40..120: errors amplify ~10x per M-H block
+        compare(rec, golden(dtype_name), name, rtol=2e-3 if big else 2e-4, atol=2e-3 if big else 2e-5)
+    else:
+        compare(rec, golden(dtype_name), name, rtol=1e-9, atol=1e-10)
