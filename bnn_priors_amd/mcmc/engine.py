@@ -107,6 +107,7 @@ class Engine:
         self.momentum_ready = False
         self.metrics_ready = False
         self.energy_ready = False
+        self.hidden_keys = frozenset()   # state keys this sampler family does not have
 
     # ------------------------------------------------------------------ views
     def _view(self, arena, i):
@@ -287,7 +288,9 @@ class SegState(dict):
         self._engine, self._index = engine, index
 
     def _lazy_available(self, key):
-        return key in self._LAZY and getattr(self._engine, self._LAZY[key][1])
+        if key not in self._LAZY or key in self._engine.hidden_keys:
+            return False
+        return getattr(self._engine, self._LAZY[key][1])
 
     def __missing__(self, key):
         if self._lazy_available(key):

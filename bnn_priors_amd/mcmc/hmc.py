@@ -14,6 +14,8 @@ class HMC(VerletSGLD):
     def __init__(self, params, lr, num_data, raise_on_no_grad=True, raise_on_nan=True, **kw):
         super().__init__(params, lr, num_data, 1., 1., raise_on_no_grad=raise_on_no_grad,
                          raise_on_nan=raise_on_nan, **kw)
+        # hmc.py:41-79 never writes state['prev_new_momentum_delta']
+        self._engine.hidden_keys = frozenset({'prev_new_momentum_delta'})
 
     def _update_group_fn(self, g):
         super()._update_group_fn(g)

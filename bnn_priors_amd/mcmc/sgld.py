@@ -89,10 +89,13 @@ class SGLD(torch.optim.Optimizer):
         if self.raise_on_nan and self._engine.nonfinite_seen():
             raise ValueError("Gradient is not finite")
 
-    def _launch(self, kind, flags, group_scalars):
+    def _launch(self, kind, flags, group_scalars, needs_momentum=True):
         """refresh tables, then one fused launch per parameter group"""
         eng = self._engine
         eng.refresh(self._preconditioners(), raise_on_no_grad=self.raise_on_no_grad)
+        if needs_momentum and not eng.momentum_ready:
+            raise RuntimeError("No 'momentum_buffer' stored in state. "
+                               "Perhaps you forgot to call `sample_momentum`?")
         if any(p.grad is None for p in eng.params):
             # raise_on_no_grad=False: the reference skips such tensors (sgld.py:96-100);
             # the fused sweep cannot, so give them a zero gradient for this launch
@@ -142,16 +145,13 @@ class SGLD(torch.optim.Optimizer):
         if len(moms) != 1:
             raise NotImplementedError("mixing momentum == 0 and momentum > 0 groups")
         has_mom = moms.pop()
-        if has_mom and not self._engine.momentum_ready:
-            raise RuntimeError("No 'momentum_buffer' stored in state. "
-                               "Perhaps you forgot to call `sample_momentum`?")
         if not has_mom and is_final and calc_metrics:
             # the reference hits an unbound local here (sgld.py:132-137)
             raise UnboundLocalError("SGLD(momentum=0).final_step(calc_metrics=True) is undefined "
                                     "in the reference (mcmc/sgld.py:132-137)")
         flags = ((_hip.FINAL if is_final else 0) | (_hip.CALC_METRICS if calc_metrics else 0)
                  | (0 if has_mom else _hip.NO_MOMENTUM))
-        self._launch(_hip.SGLD, flags, self._sgld_scalars)
+        self._launch(_hip.SGLD, flags, self._sgld_scalars, needs_momentum=has_mom)
         if calc_metrics:
             self._engine.metrics_ready = True
         return loss

@@ -41,9 +41,6 @@ class VerletSGLD(SGLD):
 
     def _transition(self, closure, flags, group_fn):
         loss = self._run_closure(closure)
-        if not self._engine.momentum_ready:
-            raise RuntimeError("No 'momentum_buffer' stored in state. "
-                               "Perhaps you forgot to call `sample_momentum`?")
 
         def scalars(g):
             group_fn(g)

@@ -288,7 +288,7 @@ DEFINE_HMC(oracle_hmc_step_f64, double, fma)
         T mn, mt;                                                                            \
         if (P->mom_decay > 0) { mn = mo * a; mn = FMA(gi, grad_lr, mn); mt = mo; }           \
         else { mn = gi * grad_lr; mt = mn; }                                                 \
-        if (P->noise_std > 0) {                                                              \
+        if (P->noise_std > 0 && !(P->flags & FLAG_FINAL)) {                                  \
           float z[4];                                                                        \
           spec_normal4(P->seed, P->stream, P->draw, 0u, (uint64_t)i >> 2, z);                \
           mn = FMA((T)z[i & 3], noise_std, mn);                                              \

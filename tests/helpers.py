@@ -45,7 +45,7 @@ class default_dtype:
         torch.set_default_dtype(self.old)
 
 
-def compare(rec, gold, name, rtol, atol, traj_rtol=None, traj_atol=None):
+def compare(rec, gold, name, rtol, atol, traj_rtol=None, traj_atol=None, u_eps=0.0):
     """accept/reject flags and step indices bit-exact; floats within tolerance."""
     g = {k.split("/", 1)[1]: v for k, v in gold.items() if k.startswith(name + "/")}
     assert np.array_equal(rec["mh_rejected"], g["mh_rejected"]), \
@@ -57,11 +57,18 @@ def compare(rec, gold, name, rtol, atol, traj_rtol=None, traj_atol=None):
     traj_atol = atol if traj_atol is None else traj_atol
     for k in ("theta", "mom", "final_theta"):
         np.testing.assert_allclose(rec[k], g[k], rtol=traj_rtol, atol=traj_atol, err_msg=f"{name}:{k}")
+    # delta_energy contains (U - U_prev) * N with U an fp32 `.item()` in the reference
+    # (verlet_sgld.py:40-41): one ulp of U moves dE by N * ulp(U).  That noise is inherent to
+    # the reference's formula; allow a few ulps of it on top of the general tolerance.
+    extra = 0.0
+    if u_eps:
+        extra = 4 * S.SCENARIOS[name]["N"] * u_eps * float(np.abs(g["loss"]).max())
     for k in ("delta_energy", "prev_delta", "est_temp", "est_cfg", "mh_delta_energy",
               "mh_log_acc", "loss", "final_precond"):
         a, b = np.asarray(rec[k], dtype=np.float64), np.asarray(g[k], dtype=np.float64)
         assert np.array_equal(np.isnan(a), np.isnan(b)), (name, k)
         assert np.array_equal(np.isinf(a), np.isinf(b)), (name, k)
         m = np.isfinite(b)
-        np.testing.assert_allclose(a[m], b[m], rtol=rtol, atol=atol, err_msg=f"{name}:{k}")
+        at = atol + (extra if k in ("mh_delta_energy", "mh_log_acc") else 0.0)
+        np.testing.assert_allclose(a[m], b[m], rtol=rtol, atol=at, err_msg=f"{name}:{k}")
     return g

@@ -130,7 +130,7 @@ def test_step_bit_exact_vs_c_oracle(kind, a, T, dtype):
                                 what=f"after {which} #{step_i}")
         dev_sums = eng.fetch_state()[:, :6]
         np.testing.assert_allclose(dev_sums, sums, rtol=1e-12, atol=1e-300)
-        if flags & FLAG_SAVE:
+        if flags & FLAG_SAVE and kind != "sgld":
             for s, p in enumerate(params):
                 st = opt.state[p]
                 assert np.array_equal(st['prev_parameter'].cpu().numpy(), fa.seg(fa.prev_theta, s))
@@ -236,6 +236,7 @@ def test_hip_reproduces_reference_goldens(name, dtype_name):
     rec = run_hip(name, dtype_name)
     if dtype_name == "float32":
         big = "biglr" in name  # lr = 40..120: errors amplify ~10x per M-H block
-        compare(rec, golden(dtype_name), name, rtol=2e-3 if big else 2e-4, atol=2e-3 if big else 2e-5)
+        compare(rec, golden(dtype_name), name, rtol=2e-3 if big else 2e-4, atol=2e-3 if big else 2e-5,
+                u_eps=2.0 ** -23)
     else:
         compare(rec, golden(dtype_name), name, rtol=1e-9, atol=1e-10)
