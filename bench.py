@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- leapfrog steps/sec of VerletSGLDReject on the MI355X path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload densenet|convnet|googleresnet]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot-loop body of the reject runner
+(bnn_priors_amd.inference_reject.VerletSGLDRunnerReject.leapfrog, reference
+inference_reject.py:86-113) over one synthetic minibatch of 128 that is already
+resident in HBM: stochastic gradient of the average potential (forward + backward,
+likelihood AND prior), the fused HIP sampler transition (momentum with friction and
+in-kernel Philox noise, position, RMSprop statistic, the six energy / temperature
+reductions), metric read-back every 10th step, cosine LR schedule.
+
+Chains are independent: rank r runs chain r on GPU r with Philox stream r and its own
+synthetic data (seed 1234 + r); no collective on the data path ("scaling": "weak").
+Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+BYTES_PER_PARAM = 28    # fp32 intermediate step: read g, m, theta, v + write m, theta, v
+
+WORKLOADS = {
+    # name: (model, x shape, N, weight prior)  -- BASELINE.json configs[1], [2], [3]
+    "densenet": ("classificationdensenet", (784,), 60000, "gaussian"),
+    "convnet": ("classificationconvnet", (784,), 60000, "laplace"),
+    "googleresnet": ("googleresnet", (3, 32, 32), 50000, "gaussian"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="densenet", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--sweep-log2", type=int, default=26, help="flat-arena roofline point, log2(elements); 0 = skip")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_data(workload, n_pool, device, seed):
+    _, xshape, _, _ = WORKLOADS[workload]
+    g = torch.Generator(device=device).manual_seed(seed)
+    if workload == "googleresnet":
+        x = torch.randn((n_pool, 128) + xshape, generator=g, device=device)
+    else:
+        x = torch.rand((n_pool, 128) + xshape, generator=g, device=device)
+    y = torch.randint(0, 10, (n_pool, 128), generator=g, device=device)
+    return [(x[i], y[i]) for i in range(n_pool)]
+
+
+def make_model(workload, device):
+    from bnn_priors_amd import models
+    name, xshape, _, prior = WORKLOADS[workload]
+    torch.manual_seed(0)
+    x0 = torch.zeros((2,) + xshape)
+    net = models.get_model(x0, torch.tensor([0, 9]), name, width=50, depth=3, weight_prior=prior,
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
+    models.he_initialize(net)
+    return net.to(device)
+
+
+class _SyntheticSet(torch.utils.data.Dataset):
+    "length-only stand-in: the runner needs len(dataset) = N and len(dataloader) = ceil(N/128)"
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def flat_arena_point(log2n, device, iters=20):
+    """The same fused kernel on ONE flat segment of 2^log2n fp32 elements (bandwidth-bound
+    regime): GB/s of algorithmic traffic (28 B/element) from HIP events."""
+    from bnn_priors_amd import mcmc
+    n = 1 << log2n
+    p = torch.nn.Parameter(torch.zeros(n, device=device))
+    p.grad = torch.full((n,), 1e-3, device=device)
+    opt = mcmc.VerletSGLD([p], lr=1e-4, num_data=1000, momentum=0.99, temperature=1.0, seed=1)
+    opt.sample_momentum()
+    opt.initial_step(save_state=False, calc_metrics=False)
+    for _ in range(3):
+        opt.step(calc_metrics=False)
+    torch.cuda.synchronize(device)
+    opt.engine.start_kernel_timing()
+    for _ in range(iters):
+        opt.step(calc_metrics=False)
+    times = [ms for ms, _, _ in opt.engine.stop_kernel_timing()]
+    avg_ms = sum(times) / len(times)
+    gbs = BYTES_PER_PARAM * n / (avg_ms * 1e-3) / 1e9
+    return dict(elements=n, avg_kernel_ms=round(avg_ms, 4), achieved_gbs=round(gbs, 1),
+                frac_of_peak=round(gbs / HBM_PEAK_GBS, 4), min_kernel_ms=round(min(times), 4))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from bnn_priors_amd.inference_reject import VerletSGLDRunnerReject
+    from bnn_priors_amd.storage import MemoryMetrics
+
+    name, xshape, N, prior = WORKLOADS[args.workload]
+    L = -(-N // 128)
+    model = make_model(args.workload, device)
+    n_params = sum(p.numel() for p in model.parameters())
+    batches = make_data(args.workload, 16, device, 1234 + rank)
+    loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
+    empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
+    runner = VerletSGLDRunnerReject(
+        model=model, dataloader=loader, dataloader_test=empty_test, epochs_per_cycle=50,
+        warmup_epochs=45, sample_epochs=5, learning_rate=0.01, skip=1, metrics_skip=10,
+        temperature=1.0, momentum=0.994, sampling_decay="cosine", cycles=60, precond_update=1,
+        metrics_saver=MemoryMetrics(), model_saver=None, reject_samples=True,
+        seed=1234, chain_id=rank)
+    # the exact initial gradient over the synthetic pool stands in for the full-data pass
+    runner._batch_source = batches
+    step = runner.begin()
+    eng = runner.optimizer.engine
+
+    def run(k, step):
+        for _ in range(k):
+            step += 1
+            x, y = batches[step % len(batches)]
+            runner.leapfrog(step, x, y, last_of_epoch=False)
+        return step
+
+    step = run(args.warmup, step)
+    if not args.no_kernel_timing:
+        eng.start_kernel_timing()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    step = run(args.steps, step)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    ktimes = [] if args.no_kernel_timing else eng.stop_kernel_timing()
+    runner._check_finite()
+    out = {
+        "metric": "leapfrog steps/sec, VerletSGLDReject", "value": round(world * args.steps / dt, 2),
+        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name} VerletSGLDReject batch=128 N={N} (L={L} steps/epoch) "
+                               f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip=10 prior={prior}",
+                   "params": n_params, "tensors": len(list(model.parameters())),
+                   "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"},
+    }
+    if rank == 0:
+        if ktimes:
+            chunks = ktimes[0][1]
+            avg_ms = sum(t for t, _, _ in ktimes) / len(ktimes)
+            algo_bytes = BYTES_PER_PARAM * n_params
+            ach = algo_bytes / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "step_kernel<float, VERLET, vec>",
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_kernel_us": round(avg_ms * 1e3, 3),
+                "launches": len(ktimes), "chunks_per_launch": chunks,
+                "regime": "launch-latency-bound: the whole sampler state of this net "
+                          f"({algo_bytes / 1e6:.2f} MB/launch) is below one launch's fixed cost; "
+                          "see roofline_flat_arena for the same kernel in its bandwidth-bound regime"}
+        if args.sweep_log2:
+            out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
+        if world == 1 and args.cpu_budget > 0:
+            from oracle.runner import time_cpu_baseline
+            cpu_batches = [(x.cpu(), y.cpu()) for x, y in batches]
+            res = time_cpu_baseline(lambda: make_model(args.workload, "cpu"), cpu_batches,
+                                    num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
+                                    steps_per_cycle=L * 50, budget_s=args.cpu_budget,
+                                    threads=os.cpu_count())
+            out["cpu_baseline"] = {
+                "value": round(res["steps_per_s"], 2), "unit": "steps/s", "cores": res["cores"],
+                "kind": "port",
+                "sample": f"{res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
+                          "(oracle/: reference-op-order torch-CPU loop, per-tensor sampler)"}
+            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,12 @@ EXPORTS = {
     "sgmcmc_abi_version": (ctypes.c_int, []),
     "sgmcmc_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "sgmcmc_step": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs), ctypes.c_void_p]),
+    "sgmcmc_step_timed": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "sgmcmc_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "sgmcmc_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.POINTER(ctypes.c_float)]),
     "sgmcmc_sample_momentum": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_double, ctypes.c_double,
                                               ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                               ctypes.c_void_p]),

@@ -536,12 +536,14 @@ int sgmcmc_abi_version(void) { return SGMCMC_ABI_VERSION; }
 
 const char* sgmcmc_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
-int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
+                      void* ev_start, void* ev_stop) {
   if (!L || !A || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
     return (int)hipErrorInvalidValue;
   if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = !(A->flags & SGMCMC_UNALIGNED);
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
   if (L->dtype == SGMCMC_F32) {
     if (vec) launch_step_kind<float, true>(*L, *A, s); else launch_step_kind<float, false>(*L, *A, s);
   } else if (L->dtype == SGMCMC_F64) {
@@ -549,9 +551,29 @@ int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream)
   } else {
     return (int)hipErrorInvalidValue;
   }
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, s);
   hipLaunchKernelGGL(finalize_step_kernel, dim3((unsigned)(A->seg_end - A->seg_begin)),
                      dim3(kThreads), 0, s, *L, *A);
   return (int)hipGetLastError();
+}
+
+int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+  return sgmcmc_step_timed(L, A, stream, nullptr, nullptr);
+}
+
+int sgmcmc_event_create(void** ev) {
+  hipEvent_t e;
+  const hipError_t err = hipEventCreate(&e);
+  if (err == hipSuccess) *ev = (void*)e;
+  return (int)err;
+}
+
+int sgmcmc_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+  hipError_t err = hipEventSynchronize((hipEvent_t)ev_stop);
+  if (err != hipSuccess) return (int)err;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
 int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint64_t seed,

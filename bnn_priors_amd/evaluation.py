@@ -1,0 +1,117 @@
+"""Posterior-predictive evaluation (SURVEY.md section 8 row f1 / e).
+
+``evaluate_model`` restates ``bnn_priors/exp_utils.py:250-340`` for the
+likelihood / accuracy outputs: for every stored sample load it, run the test
+set, keep log p(y|x) ``lps[E,N]`` and the normalised logits ``acc[E,N,C]`` in
+float64 ON THE DEVICE, then
+
+    lp_ensemble  = mean_n( logsumexp_e lps - log E )
+    ensemble logits = logsumexp_e acc - log E ,  acc = argmax == y
+
+``ensemble_across_chains`` is the one exchange step of the multi-chain path:
+each rank reduces its own samples to (max_e, sum_e exp(x - max)) and two small
+all-reduces (MAX, SUM) over RCCL combine the chains -- N_test*(C+1) doubles,
+instead of gathering [E, N, C] from every GPU.
+"""
+import math
+
+import torch
+
+__all__ = ("evaluate_model", "predictive_tables", "ensemble_across_chains", "ensemble_metrics")
+
+
+def _labels_of(dataloader):
+    ds = dataloader.dataset
+    if hasattr(ds, "tensors"):
+        return ds.tensors[1]
+    if hasattr(ds, "targets"):
+        return torch.as_tensor(ds.targets)
+    raise ValueError("I cannot find the labels in the dataloader.")
+
+
+def _n_samples(samples):
+    return min(len(v) for v in samples.values())
+
+
+@torch.no_grad()
+def predictive_tables(model, dataloader_test, samples):
+    """lps [E, N] and acc_data [E, N, C] (float64, on the model's device)."""
+    device = next(iter(model.parameters())).device
+    labels = _labels_of(dataloader_test).to(device)
+    N = labels.shape[0]
+    C = int(labels.max().item()) + 1 if labels.dim() == 1 else labels.shape[1]
+    E = _n_samples(samples)
+    lps = torch.zeros((E, N), dtype=torch.float64, device=device)
+    acc = torch.zeros((E, N, C), dtype=torch.float64, device=device)
+    kind = None
+    for e in range(E):
+        model.load_state_dict({k: v[e] for k, v in samples.items()})
+        i = 0
+        for bx, by in dataloader_test:
+            bx, by = bx.to(device), by.to(device)
+            preds = model(bx)
+            if isinstance(preds, torch.distributions.Categorical):
+                kind, a, lp = "cat", preds.logits, preds.log_prob(by)
+            elif isinstance(preds, torch.distributions.Normal):
+                kind, a, lp = "normal", preds.mean, preds.log_prob(by).sum(-1)
+            else:
+                raise ValueError(f"unknown likelihood {type(preds)}")
+            j = i + len(bx)
+            lps[e, i:j] = lp
+            acc[e, i:j] = a
+            i = j
+    return lps, acc, labels, kind
+
+
+def _log_mean_exp(t, dim):
+    return t.logsumexp(dim) - math.log(t.size(dim))
+
+
+def ensemble_metrics(model, lps, acc, labels, kind):
+    lp_each = lps.mean(1)
+    out = {"lp_ensemble": _log_mean_exp(lps, 0).mean().item(), "lp_last": lp_each[-1].item()}
+    if kind == "cat":
+        ens = torch.distributions.Categorical(logits=_log_mean_exp(acc, 0))
+        last = torch.distributions.Categorical(logits=acc[-1])
+    else:
+        ens = torch.distributions.Normal(acc.mean(0), torch.ones_like(acc[0]))
+        last = torch.distributions.Normal(acc[-1], ens.scale)
+    out["acc_ensemble"] = model.acc_mse(ens, labels).double().mean(0).item()
+    out["acc_last"] = model.acc_mse(last, labels).double().mean(0).item()
+    return out
+
+
+def evaluate_model(model, dataloader_test, samples, likelihood_eval=True, accuracy_eval=True,
+                   calibration_eval=False):
+    if calibration_eval:
+        raise NotImplementedError("calibration metrics are outside the accelerated path")
+    lps, acc, labels, kind = predictive_tables(model, dataloader_test, samples)
+    res = ensemble_metrics(model, lps, acc, labels, kind)
+    keep = (["lp_ensemble", "lp_last"] if likelihood_eval else []) + \
+           (["acc_ensemble", "acc_last"] if accuracy_eval else [])
+    return {k: res[k] for k in keep}
+
+
+@torch.no_grad()
+def ensemble_across_chains(lps, acc, group=None):
+    """Combine the per-chain tables of all ranks into the ensemble over ALL chains'
+    samples without gathering them: returns (log-mean-exp of lps [N], of acc [N, C]).
+
+    Per rank: m = max_e x, s = sum_e exp(x - m).  all_reduce(MAX) gives the global
+    max M; s * exp(m - M) summed with all_reduce(SUM), the sample counts likewise.
+    Works on any backend (RCCL on the GPUs, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    x = torch.cat([lps.unsqueeze(-1), acc], dim=-1)          # [E, N, C+1]
+    m_local = x.max(dim=0).values
+    s_local = (x - m_local).exp().sum(dim=0)
+    if dist.is_available() and dist.is_initialized():
+        m_glob = m_local.clone()
+        dist.all_reduce(m_glob, op=dist.ReduceOp.MAX, group=group)
+        packed = torch.cat([(s_local * (m_local - m_glob).exp()).reshape(-1),
+                            torch.tensor([float(x.shape[0])], dtype=x.dtype, device=x.device)])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        s_glob, count = packed[:-1].reshape(s_local.shape), packed[-1]
+    else:
+        m_glob, s_glob, count = m_local, s_local, torch.tensor(float(x.shape[0]), dtype=x.dtype)
+    lme = m_glob + s_glob.log() - count.log()
+    return lme[..., 0], lme[..., 1:]

@@ -1,0 +1,338 @@
+"""Cyclical SG-MCMC drivers on the HIP samplers: ``SGLDRunner``, ``VerletSGLDRunner``,
+``HMCRunner``.  Drop-in for ``bnn_priors/inference.py`` (reference :9-374): same
+constructor, ``run(progressbar)``, ``get_samples()``, metric keys and step numbering
+(quirks of SURVEY.md Appendix B are reproduced and marked ``# quirk``).
+
+What differs, by design (DESIGN.md "Runner"):
+* the gradient clamp (reference :219-220, one ``clamp_`` launch per tensor) is applied
+  in flight by the fused step kernel (``optimizer.grad_clamp``);
+* nothing is read back from the device on ordinary steps.  The reference's
+  per-step ``isnan(potential).item()`` (:221) becomes a device-side non-finite flag
+  that is tested whenever metrics are stored and at every epoch end, so
+  "Potential is NaN" is still raised, at most ``metrics_skip`` steps later;
+* minibatches of a ``TensorDataset`` are cut on the device from one permutation per
+  epoch, drawn with exactly the RNG calls ``RandomSampler`` would make, instead of
+  collating 128 single-example tensors per batch.
+"""
+import math
+
+import torch
+
+from . import mcmc
+from .evaluation import evaluate_model
+from .utils import get_cosine_schedule
+
+__all__ = ("SGLDRunner", "VerletSGLDRunner", "HMCRunner")
+
+
+def _is_hmc(optimizer):
+    "momentum is fully refreshed before every initial step for HMC only (inference.py:312-315)"
+    return isinstance(optimizer, mcmc.HMC) or getattr(optimizer, "is_hmc", False)
+
+
+class _BatchSource:
+    """Yields the minibatches ``dataloader`` would yield, in the same order and with
+    the same RNG consumption, but sliced on the device when the dataset allows."""
+
+    def __init__(self, dataloader, device):
+        self.dl, self.device = dataloader, device
+        ds = dataloader.dataset
+        samplers = (torch.utils.data.RandomSampler, torch.utils.data.SequentialSampler)
+        self.fast = (hasattr(ds, "tensors") and len(ds.tensors) == 2
+                     and type(dataloader.sampler) in samplers
+                     and dataloader.batch_size is not None and dataloader.num_workers == 0
+                     and dataloader.collate_fn is torch.utils.data.default_collate)
+        if self.fast:
+            self.x, self.y = (t.to(device) for t in ds.tensors)
+
+    def __len__(self):
+        return len(self.dl)
+
+    def _permutation(self):
+        s, n = self.dl.sampler, len(self.dl.dataset)
+        if isinstance(s, torch.utils.data.SequentialSampler):
+            return None
+        if s.replacement or s._num_samples is not None:
+            return torch.tensor(list(iter(s)), dtype=torch.int64)
+        if s.generator is None:   # torch/utils/data/sampler.py: RandomSampler.__iter__
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+        else:
+            gen = s.generator
+        return torch.randperm(n, generator=gen)
+
+    def __iter__(self):
+        if not self.fast:
+            for x, y in self.dl:
+                yield x.to(self.device), y.to(self.device)
+            return
+        n, bs = len(self.dl.dataset), self.dl.batch_size
+        # DataLoader.__iter__ draws a worker base seed before the sampler runs
+        # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__): keep the global
+        # RNG stream aligned with a run that iterates the DataLoader itself
+        torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
+        perm = self._permutation()
+        if perm is not None:
+            perm = perm.to(self.device)
+        stop = n - n % bs if self.dl.drop_last else n
+        for i in range(0, stop, bs):
+            if perm is None:
+                yield self.x[i:i + bs], self.y[i:i + bs]
+            else:
+                idx = perm[i:i + bs]
+                yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+
+
+class SGLDRunner:
+    """Stochastic Gradient Langevin Dynamics for posterior sampling; arguments as the
+    reference (bnn_priors/inference.py:10-58).  Extra keyword-only arguments:
+    ``seed`` / ``chain_id`` for the in-kernel Philox noise."""
+    _OPTIMIZER = mcmc.SGLD
+
+    def __init__(self, model, dataloader, dataloader_test, epochs_per_cycle, warmup_epochs,
+                 sample_epochs, learning_rate=1e-2, skip=1, metrics_skip=1, temperature=1.,
+                 data_mult=1., momentum=0., sampling_decay=True, grad_max=1e6, cycles=1,
+                 precond_update=None, metrics_saver=None, model_saver=None, reject_samples=False,
+                 *, seed=None, chain_id=0):
+        self.model, self.dataloader, self.dataloader_test = model, dataloader, dataloader_test
+        assert warmup_epochs >= 0
+        assert sample_epochs >= 0
+        assert epochs_per_cycle >= warmup_epochs + sample_epochs
+        self.epochs_per_cycle = epochs_per_cycle
+        self.descent_epochs = epochs_per_cycle - warmup_epochs - sample_epochs
+        self.warmup_epochs, self.sample_epochs = warmup_epochs, sample_epochs
+        self.skip, self.metrics_skip = skip, metrics_skip
+        self.num_samples = sample_epochs // skip
+        assert sample_epochs % skip == 0
+        self.learning_rate, self.temperature = learning_rate, temperature
+        self.eff_num_data = len(dataloader.dataset) * data_mult
+        self.momentum, self.sampling_decay, self.grad_max = momentum, sampling_decay, grad_max
+        self.cycles, self.precond_update = cycles, precond_update
+        self.metrics_saver, self.model_saver = metrics_saver, model_saver
+        if model_saver is None:
+            self._samples = {
+                name: torch.zeros(torch.Size([self.num_samples * cycles]) + t.shape, dtype=t.dtype)
+                for name, t in model.state_dict().items()}
+            self._samples["steps"] = torch.zeros(torch.Size([self.num_samples * cycles]),
+                                                 dtype=torch.int64)
+        self.param_names, self._params = zip(*model.named_parameters())
+        self.reject_samples = reject_samples
+        self.seed, self.chain_id = seed, chain_id
+        self._device = self._params[0].device
+
+    # ------------------------------------------------------------------ factories
+    def _sampler_kwargs(self):
+        return dict(seed=self.seed, chain_id=self.chain_id, grad_clamp=self.grad_max or 0.0)
+
+    def _make_optimizer(self, params):
+        assert self.reject_samples is False, "SGLD cannot reject samples"
+        return mcmc.SGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                         momentum=self.momentum, temperature=self.temperature,
+                         **self._sampler_kwargs())
+
+    def _make_scheduler(self, optimizer):
+        # inference.py:96-108
+        if self.sampling_decay is True or self.sampling_decay == "cosine":
+            schedule = get_cosine_schedule(len(self.dataloader) * self.epochs_per_cycle)
+            return torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
+        elif self.sampling_decay is False or self.sampling_decay == "stairs":
+            return torch.optim.lr_scheduler.StepLR(optimizer, 150 * len(self.dataloader), gamma=0.1)
+        elif self.sampling_decay == "flat":
+            return torch.optim.lr_scheduler.StepLR(optimizer, 2 ** 30, gamma=1.0)
+        raise ValueError(f"self.sampling_decay={self.sampling_decay}")
+
+    def _is_sampling_epoch(self, epoch):
+        epoch = epoch % self.epochs_per_cycle
+        k = epoch - (self.descent_epochs + self.warmup_epochs)
+        return (0 <= k) and (k % self.skip == 0)
+
+    def _batches(self):
+        try:
+            return self._batch_source
+        except AttributeError:
+            self._batch_source = _BatchSource(self.dataloader, self._device)
+            return self._batch_source
+
+    # ------------------------------------------------------------------ the run
+    def run(self, progressbar=False):
+        "inference.py:110-187"
+        self.optimizer = self._make_optimizer(self._params)
+        self.optimizer.sample_momentum()
+        self.scheduler = self._make_scheduler(self.optimizer)
+        self.metrics_saver.add_scalar("test/log_prob", math.nan, step=-1)
+        self.metrics_saver.add_scalar("test/acc", math.nan, step=-1)
+
+        step = -1
+        for cycle in range(self.cycles):
+            for epoch in range(self.epochs_per_cycle):
+                for g in self.optimizer.param_groups:
+                    g['temperature'] = 0. if epoch < self.descent_epochs else self.temperature
+                for i, (x, y) in enumerate(self._batches()):
+                    step += 1
+                    store_metrics = (i == 0 or step % self.metrics_skip == 0)
+                    initial_step = (step == 0 or (i == 0 and self._is_sampling_epoch(epoch - 1)))
+                    self.step(step, x.detach(), y.detach(), store_metrics=store_metrics,
+                              initial_step=initial_step)
+                if self.precond_update is not None and epoch % self.precond_update == 0:
+                    self.optimizer.update_preconditioner()
+                self._check_finite()
+                state_dict = self.model.state_dict()
+                if self._is_sampling_epoch(epoch):
+                    self._save_sample(state_dict, cycle, epoch, step)
+                self._evaluate_model(state_dict, step)
+                self.metrics_saver.flush(every_s=10)
+        # metrics for the last sample (inference.py:182-187)
+        x, y = next(iter(self._batches()))
+        self.step(step + 1, x, y, store_metrics=True, initial_step=self._is_sampling_epoch(-1))
+
+    def _save_sample(self, state_dict, cycle, epoch, step):
+        k = epoch - (self.descent_epochs + self.warmup_epochs)
+        if self.model_saver is None:
+            row = self.num_samples * cycle + k // self.skip
+            for name, t in state_dict.items():
+                self._samples[name][row] = t
+        else:
+            self.model_saver.add_state_dict(state_dict, step)
+            self.model_saver.flush()
+
+    def _evaluate_model(self, state_dict, step):
+        if len(self.dataloader_test) == 0:
+            return {}
+        self.model.eval()
+        one = {k: v.unsqueeze(0) for k, v in state_dict.items()}
+        res = evaluate_model(self.model, self.dataloader_test, one, likelihood_eval=True,
+                             accuracy_eval=True, calibration_eval=False)
+        self.model.train()
+        res = {"test/loss": -res["lp_last"], "test/acc": res["acc_last"]}
+        for k, v in res.items():
+            self.metrics_saver.add_scalar(k, v, step)
+        return res
+
+    def _check_finite(self):
+        if self.optimizer.engine.nonfinite_seen():
+            raise ValueError("Potential is NaN")
+
+    def _model_potential_and_grad(self, x, y):
+        """zero grads, potential_avg forward/backward.  The +-grad_max clamp of
+        inference.py:219-220 happens inside the step kernel; the NaN test of :221 is
+        the deferred ``_check_finite``.  Returns device tensors (no sync)."""
+        self.optimizer.zero_grad()
+        loss, log_prior, potential, accs, _ = self.model.split_potential_and_acc(
+            x, y, self.eff_num_data)
+        potential.backward()
+        return loss, log_prior, potential, accs.mean()
+
+    def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
+        "inference.py:225-249"
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
+        self.optimizer.step(calc_metrics=store_metrics)
+        lr = self.optimizer.param_groups[0]["lr"]
+        if lr_decay:
+            self.scheduler.step()
+        if store_metrics:
+            self._check_finite()
+            self.store_metrics(i=i - 1, loss=loss.item(), log_prior=log_prior.item(),   # quirk 6
+                               potential=potential.item(), acc=acc.item(), lr=lr,
+                               corresponds_to_sample=initial_step)
+        return loss, acc, None
+
+    def get_samples(self):
+        if self.model_saver is None:
+            return {k: v for k, v in self._samples.items() if k != "steps"}
+        return self.model_saver.load_samples(keep_steps=False)
+
+    def store_metrics(self, i, loss, log_prior, potential, acc, lr, corresponds_to_sample,
+                      delta_energy=None, total_energy=None, rejected=None):
+        "inference.py:262-294; one D2H copy serves every per-tensor scalar below"
+        add = self.metrics_saver.add_scalar
+        t_all = c_all = 0.
+        numel = 0
+        for n, p in zip(self.param_names, self.optimizer.param_groups[0]["params"]):
+            st = self.optimizer.state[p]
+            add("preconditioner/" + n, st["preconditioner"], i)
+            add("est_temperature/" + n, st["est_temperature"], i)
+            add("est_config_temp/" + n, st["est_config_temp"], i)
+            t_all += st["est_temperature"] * p.numel()
+            c_all += st["est_config_temp"] * p.numel()
+            numel += p.numel()
+        add("est_temperature/all", t_all / numel, i)
+        add("est_config_temp/all", c_all / numel, i)
+        add("temperature", self.optimizer.param_groups[0]["temperature"], i)
+        add("loss", loss, i)
+        add("acc", acc, i)
+        add("log_prior", log_prior, i)
+        add("potential", potential, i)
+        add("lr", lr, i)
+        add("acceptance/is_sample", int(corresponds_to_sample), i)
+        if delta_energy is not None:
+            add("delta_energy", delta_energy, i)
+            add("total_energy", total_energy, i)
+        if rejected is not None:
+            add("acceptance/rejected", int(rejected), i)
+
+
+class VerletSGLDRunner(SGLDRunner):
+    "inference.py:297-365: stochastic-gradient energy differences ('illustrative' M-H)"
+
+    def _make_optimizer(self, params):
+        return mcmc.VerletSGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                               momentum=self.momentum, temperature=self.temperature,
+                               **self._sampler_kwargs())
+
+    def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
+        lr = self.optimizer.param_groups[0]["lr"]
+        opt, is_hmc = self.optimizer, _is_hmc(self.optimizer)
+        rejected = delta_energy = None
+        if i == 0:
+            if is_hmc:
+                opt.sample_momentum()
+            opt.initial_step(calc_metrics=True, save_state=self.reject_samples)
+            if self.reject_samples:
+                rejected = False
+        elif initial_step:
+            opt.final_step(calc_metrics=True)
+            delta_energy = opt.delta_energy(self._initial_potential, potential)
+            if self.reject_samples:
+                rejected, _ = opt.maybe_reject(delta_energy)
+            if is_hmc:
+                opt.sample_momentum()
+            opt.initial_step(calc_metrics=False, save_state=self.reject_samples)
+        else:
+            opt.step(calc_metrics=store_metrics)
+
+        if i == 0:
+            store_metrics = True
+            total_energy = delta_energy = opt.delta_energy(0., 0.)                # quirk 13
+            self._initial_potential = potential.item()
+            self._total_energy = 0.
+        elif initial_step:
+            store_metrics = True
+            self._initial_potential = potential.item()                            # quirk 1
+            self._total_energy += delta_energy
+            total_energy = self._total_energy
+        elif store_metrics:
+            delta_energy = opt.delta_energy(self._initial_potential, loss)        # quirk 13
+            total_energy = self._total_energy + delta_energy
+
+        if store_metrics:
+            self._check_finite()
+            self.store_metrics(i=i - 1, loss=loss.item(), log_prior=log_prior.item(),
+                               potential=potential.item(), acc=acc.item(), lr=lr,
+                               delta_energy=delta_energy, total_energy=total_energy,
+                               rejected=rejected, corresponds_to_sample=initial_step)
+        if lr_decay:
+            self.scheduler.step()
+        return loss, acc, delta_energy
+
+
+class HMCRunner(VerletSGLDRunner):
+    def _make_optimizer(self, params):
+        # inference.py:367-374
+        assert self.temperature == 1.0, "HMC only implemented for temperature=1."
+        assert self.momentum == 1.0, "HMC only works with momentum=1."
+        assert self.descent_epochs == 0, "HMC not implemented for descent epochs with temp=0."
+        kw = self._sampler_kwargs()
+        return mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                        raise_on_nan=False, **kw)

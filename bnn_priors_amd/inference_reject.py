@@ -1,0 +1,174 @@
+"""Exact-gradient Metropolis-Hastings drivers: ``VerletSGLDRunnerReject``,
+``HMCRunnerReject``, ``SGLDRunnerReject``.  Drop-in for
+``bnn_priors/inference_reject.py`` (reference :11-198): minibatch leapfrog steps
+inside an epoch, a full-data gradient + ``final_step`` + M-H test at every stored
+sample, one fixed minibatch order per cycle.
+
+``leapfrog()`` is the hot-loop body (reference :86-113) and what ``bench.py`` times.
+"""
+import torch
+
+from . import mcmc
+from .inference import SGLDRunner, _is_hmc
+
+__all__ = ("VerletSGLDRunnerReject", "HMCRunnerReject", "SGLDRunnerReject")
+
+
+class VerletSGLDRunnerReject(SGLDRunner):
+    def __init__(self, *a, cycle_seed=None, **kw):
+        """``cycle_seed``: None reproduces the reference (a fresh non-deterministic
+        shuffle seed per cycle, inference_reject.py:72); an int pins cycle c's seed to
+        ``cycle_seed + c`` so that runs (and parity tests) are repeatable."""
+        super().__init__(*a, **kw)
+        self.cycle_seed = cycle_seed
+
+    def _make_optimizer(self, params):
+        return mcmc.VerletSGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                               momentum=self.momentum, temperature=self.temperature,
+                               **self._sampler_kwargs())
+
+    def _exact_model_potential_and_grad(self, batches):
+        """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N], accumulated by
+        autograd over the whole loader (inference_reject.py:18-33)."""
+        self.optimizer.zero_grad()
+        log_prior = self.model.log_prior()
+        log_norm_prior = log_prior / -self.eff_num_data
+        log_norm_prior.backward()
+        loss = 0.
+        for x, y in batches:
+            this_loss = self.model.log_likelihood(x, y, -x.size(0) / self.eff_num_data)
+            this_loss.backward()
+            loss = loss + this_loss.detach()
+        return loss, log_prior.detach(), loss + log_norm_prior.detach()
+
+    def leapfrog(self, step, x, y, last_of_epoch):
+        """One minibatch leapfrog step: stochastic gradient, fused sampler transition,
+        metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
+        store = (step % self.metrics_skip) == 0
+        self.optimizer.step(calc_metrics=store)
+        if store:
+            self._check_finite()
+            delta_energy = self.optimizer.delta_energy(self._initial_potential, potential)
+            self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
+                               potential=potential.item(), acc=acc.item(),
+                               lr=self.optimizer.param_groups[0]["lr"],
+                               corresponds_to_sample=False, delta_energy=delta_energy,
+                               total_energy=self._total_energy + delta_energy)
+        if not last_of_epoch:   # the last scheduler step of an epoch follows final_step
+            self.scheduler.step()
+        return acc
+
+    def begin(self):
+        """optimizer, scheduler, exact initial gradient, momentum draw and the first
+        ``initial_step`` (inference_reject.py:36-66); returns the step counter (0)."""
+        self.optimizer = opt = self._make_optimizer(self._params)
+        self.scheduler = self._make_scheduler(opt)
+        loss, log_prior, potential = self._exact_model_potential_and_grad(self._batches())
+        opt.sample_momentum()
+        opt.initial_step(calc_metrics=True, save_state=self.reject_samples)
+        self._check_finite()
+        self.store_metrics(i=0, loss=loss.item(), log_prior=log_prior.item(),
+                           potential=potential.item(), acc=0.,                      # quirk 5
+                           lr=opt.param_groups[0]["lr"], corresponds_to_sample=True,
+                           delta_energy=0., total_energy=0., rejected=False)
+        self._initial_potential = potential.item()
+        self._total_energy = 0.
+        return 0
+
+    def run(self, progressbar=False):
+        "inference_reject.py:35-179"
+        step = self.begin()
+        opt, batches = self.optimizer, self._batches()
+
+        def enter_epoch(temperature):
+            for g in opt.param_groups:
+                g['temperature'] = temperature
+
+        assert self.dataloader.sampler.generator is None
+        generator = self.dataloader.sampler.generator = torch.Generator()
+        acc = torch.zeros(())
+        try:
+            for cycle in range(self.cycles):
+                if self.cycle_seed is None:
+                    generator.seed()
+                else:
+                    generator.manual_seed(self.cycle_seed + cycle)
+                cycle_random_state = generator.get_state()
+                for epoch in range(self.epochs_per_cycle):
+                    if epoch < self.descent_epochs:
+                        enter_epoch(0.)
+                    else:
+                        enter_epoch(self.temperature)
+                    # same minibatch order in every epoch of the cycle (:84)
+                    generator.set_state(cycle_random_state)
+                    n_batches = len(batches)
+                    for i, (x, y) in enumerate(batches):
+                        step += 1
+                        acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
+
+                    if self._is_sampling_epoch(epoch):
+                        step += 1                                                    # quirk 6
+                        loss, log_prior, potential = self._exact_model_potential_and_grad(batches)
+                        opt.final_step(calc_metrics=True)
+                        delta_energy = opt.delta_energy(self._initial_potential, potential)
+                        self._total_energy += delta_energy
+                        self._initial_potential = potential.item()                   # quirk 1
+                        rejected = False
+                        if self.reject_samples:
+                            rejected, _ = opt.maybe_reject(delta_energy)
+                        self._check_finite()
+                        self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
+                                           potential=potential.item(), acc=acc.item(),  # quirk 5
+                                           lr=opt.param_groups[0]["lr"],
+                                           corresponds_to_sample=True, delta_energy=delta_energy,
+                                           total_energy=self._total_energy, rejected=rejected)
+                        state_dict = self.model.state_dict()
+                        self._evaluate_model(state_dict, step)
+                        self._save_sample(state_dict, cycle, epoch, step)
+                        self.scheduler.step()
+                        # first step of the next epoch: same gradient, next learning rate (:152-157)
+                        if _is_hmc(opt):
+                            opt.sample_momentum()
+                        opt.initial_step(calc_metrics=False, save_state=self.reject_samples)
+                    else:
+                        self._evaluate_model(self.model.state_dict(), step)
+                        self.scheduler.step()
+
+                    if self.precond_update is not None and (epoch + 1) % self.precond_update == 0:
+                        opt.update_preconditioner()
+                    self._check_finite()
+                    self.metrics_saver.flush(every_s=30)
+        finally:
+            self.dataloader.sampler.generator = None
+
+
+class HMCRunnerReject(VerletSGLDRunnerReject):
+    def _make_optimizer(self, params):
+        # inference_reject.py:182-189
+        assert self.temperature == 1.0, "HMC only implemented for temperature=1."
+        assert self.momentum == 1.0, "HMC only works with momentum=1."
+        assert self.descent_epochs == 0, "HMC not implemented for descent epochs with temp=0."
+        return mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                        raise_on_nan=False, **self._sampler_kwargs())
+
+
+class SGLDRunnerReject(VerletSGLDRunnerReject):
+    def _make_optimizer(self, params):
+        # inference_reject.py:191-198
+        assert not self.reject_samples
+        return mcmc.SGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                         momentum=self.momentum, temperature=self.temperature,
+                         **self._sampler_kwargs())
+
+
+# name -> runner class, as experiments/train_bnn.py:223-234 selects them
+def runner_class(inference):
+    from . import inference as plain
+    table = {"SGLD": plain.SGLDRunner, "VerletSGLD": plain.VerletSGLDRunner,
+             "OurHMC": plain.HMCRunner, "HMCReject": HMCRunnerReject,
+             "VerletSGLDReject": VerletSGLDRunnerReject, "SGLDReject": SGLDRunnerReject}
+    try:
+        return table[inference]
+    except KeyError:
+        raise ValueError(f"Unknown inference method {inference}") from None

@@ -223,9 +223,46 @@ class Engine:
                           num_data=num_data, b2h2=b2h2, bh=bh, bhn=bhn, mom_decay=mom_decay,
                           grad_v=grad_v, noise_std=noise_std, rmsprop_alpha=rmsprop_alpha,
                           grad_clamp=grad_clamp, seed=self.seed, draw=draw, stream=self.chain_id)
-        _hip.check(self.lib.sgmcmc_step(ctypes.byref(self.layout), ctypes.byref(A), self.stream()),
-                   "sgmcmc_step")
+        if self.kernel_timing:
+            e0, e1 = self._event_pair()
+            _hip.check(self.lib.sgmcmc_step_timed(ctypes.byref(self.layout), ctypes.byref(A),
+                                                  self.stream(), e0, e1), "sgmcmc_step_timed")
+            self._timed.append((e0, e1, (c1 - c0), flags))
+        else:
+            _hip.check(self.lib.sgmcmc_step(ctypes.byref(self.layout), ctypes.byref(A),
+                                            self.stream()), "sgmcmc_step")
         self._touch()
+
+    # ---- live kernel timing (bench.py roofline): HIP events around the fused update kernel
+    kernel_timing = False
+
+    def _event_pair(self):
+        if not hasattr(self, "_event_pool"):
+            self._event_pool, self._timed = [], []
+        out = []
+        for _ in range(2):
+            ev = ctypes.c_void_p()
+            _hip.check(self.lib.sgmcmc_event_create(ctypes.byref(ev)), "event_create")
+            out.append(ev)
+            self._event_pool.append(ev)
+        return out
+
+    def start_kernel_timing(self):
+        self.kernel_timing = True
+        self._event_pool, self._timed = getattr(self, "_event_pool", []), []
+
+    def stop_kernel_timing(self):
+        """-> list of (milliseconds, chunks, flags) for every fused-kernel launch since start"""
+        self.kernel_timing = False
+        out = []
+        for e0, e1, n_chunks, flags in self._timed:
+            ms = ctypes.c_float()
+            _hip.check(self.lib.sgmcmc_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "event_elapsed")
+            out.append((ms.value, n_chunks, flags))
+        for ev in self._event_pool:
+            self.lib.sgmcmc_event_destroy(ev)
+        self._event_pool, self._timed = [], []
+        return out
 
     def sample_momentum(self, std, keep, draw):
         _hip.check(self.lib.sgmcmc_sample_momentum(ctypes.byref(self.layout), std, keep, self.seed,

@@ -131,6 +131,16 @@ const char* sgmcmc_error_string(int err);
  * HMC._step_fn (mcmc/hmc.py:41-79). */
 int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream);
 
+/* As sgmcmc_step, additionally recording ev_start immediately before and ev_stop
+ * immediately after the fused update kernel (not the finalize kernel) on `stream`, so a
+ * caller can measure that kernel's duration live (bench.py roofline).  Events are
+ * hipEvent_t created by sgmcmc_event_create. */
+int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
+                      void* ev_start, void* ev_stop);
+int sgmcmc_event_create(void** ev);
+int sgmcmc_event_destroy(void* ev);
+int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+
 /* m <- sqrt(keep)*m + std*xi   (keep == 0: m <- std*xi).
  * Replaces SGLD.sample_momentum (mcmc/sgld.py:57-69). */
 int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint64_t seed,

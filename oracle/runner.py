@@ -1,0 +1,71 @@
+"""Reference-op-order CPU leapfrog loop (TEST INFRASTRUCTURE; bench.py cpu_baseline).
+
+``cpu_leapfrog`` is the hot-loop body of the reference's reject runner, statement by
+statement -- eager torch-CPU forward/backward, per-tensor ``clamp_``, the blocking
+``isnan(potential).item()``, the per-tensor sampler loop with its ``.item()`` dots, the
+metric read-backs every ``metrics_skip`` steps and the scheduler step
+(bnn_priors/inference.py:215-223, bnn_priors/inference_reject.py:86-113) -- so that the
+timed CPU figure is neither flattered nor handicapped.
+"""
+import time
+
+import torch
+
+from .samplers import RefVerletSGLD
+
+
+def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metrics_skip=10,
+                 initial_potential=0.0):
+    opt.zero_grad()
+    loss, log_prior, potential, accs, _ = model.split_potential_and_acc(x, y, num_data)
+    potential.backward()
+    for p in opt.param_groups[0]["params"]:
+        p.grad.clamp_(min=-grad_max, max=grad_max)
+    if torch.isnan(potential).item():
+        raise ValueError("Potential is NaN")
+    store = (step % metrics_skip) == 0
+    opt.step(calc_metrics=store)
+    if store:
+        de = opt.delta_energy(initial_potential, potential)
+        _ = (loss.item(), log_prior.item(), potential.item(), accs.mean().item(), de)
+        for p in opt.param_groups[0]["params"]:
+            st = opt.state[p]
+            _ = (st["preconditioner"], st["est_temperature"], st["est_config_temp"])
+    scheduler.step()
+
+
+def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperature, steps_per_cycle,
+                      budget_s=12.0, warmup=5, min_steps=30, threads=None):
+    """Run the loop above on the host for about ``budget_s`` seconds; returns
+    dict(steps_per_s, steps, seconds, cores)."""
+    from bnn_priors_amd.utils import get_cosine_schedule  # a pure function of i (utils.py:5-10)
+    if threads:
+        torch.set_num_threads(threads)
+    model = make_model()
+    params = list(model.parameters())
+    opt = RefVerletSGLD(params, lr=lr, num_data=num_data, momentum=momentum,
+                        temperature=temperature)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, get_cosine_schedule(steps_per_cycle))
+    # exact-gradient stand-in for the initial step: one minibatch gradient is enough to
+    # put the sampler into its steady state
+    x, y = batches[0]
+    opt.zero_grad()
+    model.split_potential_and_acc(x, y, num_data)[2].backward()
+    opt.sample_momentum()
+    opt.initial_step(calc_metrics=True, save_state=True)
+    step = 0
+    for _ in range(warmup):
+        step += 1
+        x, y = batches[step % len(batches)]
+        cpu_leapfrog(model, opt, sched, x, y, step, num_data)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step += 1
+        n += 1
+        x, y = batches[step % len(batches)]
+        cpu_leapfrog(model, opt, sched, x, y, step, num_data)
+        if n >= min_steps and time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(steps_per_s=n / dt, steps=n, seconds=dt, cores=torch.get_num_threads())
