@@ -197,11 +197,11 @@ def main():
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in batches]
             res = time_cpu_baseline(lambda: make_model(args.workload, "cpu"), cpu_batches,
                                     num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
-                                    steps_per_cycle=L * 50, budget_s=args.cpu_budget,
-                                    threads=os.cpu_count())
+                                    steps_per_cycle=L * 50, budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
                 "value": round(res["steps_per_s"], 2), "unit": "steps/s", "cores": res["cores"],
-                "kind": "port",
+                "kind": "port", "host_cpus": res["host_cpus"],
+                "threads_calibration_steps_per_s": res["calibration"],
                 "sample": f"{res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
                           "(oracle/: reference-op-order torch-CPU loop, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)

@@ -34,30 +34,23 @@ def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metr
     scheduler.step()
 
 
-def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperature, steps_per_cycle,
-                      budget_s=12.0, warmup=5, min_steps=30, threads=None):
-    """Run the loop above on the host for about ``budget_s`` seconds; returns
-    dict(steps_per_s, steps, seconds, cores)."""
+def _setup(make_model, batches, num_data, lr, momentum, temperature, steps_per_cycle):
     from bnn_priors_amd.utils import get_cosine_schedule  # a pure function of i (utils.py:5-10)
-    if threads:
-        torch.set_num_threads(threads)
     model = make_model()
-    params = list(model.parameters())
-    opt = RefVerletSGLD(params, lr=lr, num_data=num_data, momentum=momentum,
+    opt = RefVerletSGLD(list(model.parameters()), lr=lr, num_data=num_data, momentum=momentum,
                         temperature=temperature)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, get_cosine_schedule(steps_per_cycle))
-    # exact-gradient stand-in for the initial step: one minibatch gradient is enough to
-    # put the sampler into its steady state
+    # one minibatch gradient stands in for the exact initial gradient: enough to put the
+    # sampler into its steady state
     x, y = batches[0]
     opt.zero_grad()
     model.split_potential_and_acc(x, y, num_data)[2].backward()
     opt.sample_momentum()
     opt.initial_step(calc_metrics=True, save_state=True)
-    step = 0
-    for _ in range(warmup):
-        step += 1
-        x, y = batches[step % len(batches)]
-        cpu_leapfrog(model, opt, sched, x, y, step, num_data)
+    return model, opt, sched
+
+
+def _timed_loop(model, opt, sched, batches, num_data, step, budget_s, min_steps):
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -67,5 +60,35 @@ def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperatur
         cpu_leapfrog(model, opt, sched, x, y, step, num_data)
         if n >= min_steps and time.perf_counter() - t0 >= budget_s:
             break
-    dt = time.perf_counter() - t0
-    return dict(steps_per_s=n / dt, steps=n, seconds=dt, cores=torch.get_num_threads())
+    return n, time.perf_counter() - t0, step
+
+
+def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperature, steps_per_cycle,
+                      budget_s=12.0, warmup=5, min_steps=20, thread_choices=(1, 2, 4, 8, 16, 32, 64)):
+    """Run the loop above on the host for about ``budget_s`` seconds with the thread count
+    that is fastest for this workload (a short calibration over ``thread_choices`` first:
+    tiny nets get SLOWER with more OpenMP threads, and the baseline must not be handicapped).
+    Returns dict(steps_per_s, steps, seconds, cores, calibration)."""
+    import os
+    ncpu = os.cpu_count() or 1
+    model, opt, sched = _setup(make_model, batches, num_data, lr, momentum, temperature,
+                               steps_per_cycle)
+    step = 0
+    calib = {}
+    for t in [c for c in thread_choices if c <= ncpu]:
+        torch.set_num_threads(t)
+        for _ in range(2):
+            step += 1
+            x, y = batches[step % len(batches)]
+            cpu_leapfrog(model, opt, sched, x, y, step, num_data)
+        n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, 1.0, 3)
+        calib[t] = n / dt
+    best = max(calib, key=calib.get)
+    torch.set_num_threads(best)
+    for _ in range(warmup):
+        step += 1
+        x, y = batches[step % len(batches)]
+        cpu_leapfrog(model, opt, sched, x, y, step, num_data)
+    n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, budget_s, min_steps)
+    return dict(steps_per_s=n / dt, steps=n, seconds=dt, cores=best, host_cpus=ncpu,
+                calibration={str(k): round(v, 1) for k, v in calib.items()})

@@ -29,7 +29,7 @@ def _runner_class(name):
     return inference_reject.runner_class(RC.CASES[name].get("runner", name))
 
 
-def _check(name, metrics, runner, rtol, atol, de_atol):
+def _check(name, metrics, runner, rtol, atol, de_atol, acc_atol=0.0):
     g = gold()
     got = RC.streams_of(metrics)
     want_keys = sorted({k.split("/", 1)[1].rsplit("/", 1)[0] for k in g
@@ -47,6 +47,8 @@ def _check(name, metrics, runner, rtol, atol, de_atol):
             fin = np.isfinite(gv)
             assert np.array_equal(np.isfinite(v), fin), (name, k)
             at = de_atol if k in ("delta_energy", "total_energy") else atol
+            if k in ("acc", "test/acc"):
+                at = max(at, acc_atol)    # discrete: one near-tie argmax flips 1/128 (1/256)
             np.testing.assert_allclose(v[fin], gv[fin], rtol=rtol, atol=at, err_msg=f"{name}:{k}")
     samples = runner.get_samples()
     first = next(iter(k for k in samples if k.endswith("0.weight_prior.p")))
@@ -121,4 +123,4 @@ def test_runner_on_gpu_matches_reference_goldens(name):
     # inside _check.  Floats: N = 1024 multiplies one fp32 ulp of the potential (U ~ 60) into
     # ~8e-3 of delta_energy (inherent to the reference's formula); the
     # GPU's GEMM / reduction order differs from the CPU's, so allow a few of those.
-    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5)
+    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128)
