@@ -81,6 +81,8 @@ EXPORTS = {
                                            ctypes.c_void_p]),
     "sgmcmc_segment_sum": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_int, ctypes.c_uint32,
                                           ctypes.c_void_p]),
+    "sgmcmc_prior_grad": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_double, ctypes.c_int,
+                                         ctypes.c_uint32, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -496,6 +496,81 @@ __global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L,
   else st->point_energy = .5 * S[0];
 }
 
+// ------------------------------------------------------------------ fused priors
+// d/dtheta of -log p(theta)/N and (optionally) log p(theta), element-wise families with scalar
+// loc/scale/df (SURVEY.md Appendix A "Priors").  The gradient is applied in the working precision
+// with one rounding for the factor and one fma into g; log p is evaluated and accumulated in fp64.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double num_data,
+                                                         int calc_logp) {
+  const int64_t chunk = blockIdx.x;
+  const ChunkCtx cx = chunk_ctx(L, chunk);
+  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+  const int kind = sp->prior_kind;
+  double acc[1] = {0.0};
+  if (kind != SGMCMC_PRIOR_NONE) {
+    T* __restrict__ gp = (T*)sp->g + cx.seg_off;
+    const T* __restrict__ thp = (const T*)sp->theta + cx.seg_off;
+    const double loc = sp->prior_loc, scale = sp->prior_scale, df = sp->prior_df;
+    const T locT = (T)loc;
+    const T c_normal = (T)(1.0 / (scale * scale * num_data));
+    const T c_laplace = (T)(1.0 / (scale * num_data));
+    const T c_t_num = (T)((df + 1.0) / num_data), c_t_den = (T)(df * scale * scale);
+    for (int it = 0; it < kItems; ++it) {
+      const int j = (it * kThreads + threadIdx.x) * 4;
+      const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
+      if (n <= 0) break;
+      Item<T> g = load_guarded<T>(gp + j, n);
+      const Item<T> th = load_guarded<T>(thp + j, n);
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        if (l < n) {
+          const T d = th.x[l] - locT;
+          if (kind == SGMCMC_PRIOR_NORMAL) {
+            g.x[l] = fma_t<T>(d, c_normal, g.x[l]);
+          } else if (kind == SGMCMC_PRIOR_LAPLACE) {
+            const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
+            g.x[l] = fma_t<T>(sgn, c_laplace, g.x[l]);
+          } else {
+            g.x[l] = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g.x[l]);
+          }
+          if (calc_logp) {
+            const double z = ((double)th.x[l] - loc) / scale;
+            if (kind == SGMCMC_PRIOR_NORMAL) acc[0] += -0.5 * z * z;
+            else if (kind == SGMCMC_PRIOR_LAPLACE) acc[0] += -fabs(z);
+            else acc[0] += -0.5 * (df + 1.0) * log1p(z * z / df);
+          }
+        }
+      }
+      store_guarded<T>(gp + j, g, n);
+    }
+  }
+  if (calc_logp) block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_NSUMS);
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_prior_kernel(sgmcmc_layout L) {
+  const int seg = blockIdx.x;
+  const sgmcmc_segment s = L.segs[seg];
+  double S[1];
+  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  if (threadIdx.x != 0) return;
+  double norm = 0.0;  // per-element normalising constant of the density
+  const double n = (double)s.numel;
+  if (s.prior_kind == SGMCMC_PRIOR_NORMAL) norm = -log(s.prior_scale) - 0.9189385332046727418;
+  else if (s.prior_kind == SGMCMC_PRIOR_LAPLACE) norm = -log(2.0 * s.prior_scale);
+  else if (s.prior_kind == SGMCMC_PRIOR_STUDENT_T)
+    norm = -log(s.prior_scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
+           lgamma(0.5 * s.prior_df) + lgamma(0.5 * (s.prior_df + 1.0));
+  L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + n * norm;
+}
+
+__global__ void total_prior_kernel(sgmcmc_layout L) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;
+  for (int s = 0; s < L.n_seg; ++s) total += L.state[s].aux;
+  L.scalars[2] = total;
+}
+
 __global__ void total_energy_kernel(sgmcmc_layout L) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double total = 0.0;  // verlet_sgld.py:32-38, same association as the reference's Python loop
@@ -628,6 +703,23 @@ int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* 
   int err = launch_dot(L, which, 0.0, s);
   if (err) return err;
   hipLaunchKernelGGL(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L, 0, 0.0, 0.0);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob, uint32_t flags,
+                      void* stream) {
+  (void)flags;
+  if (!L || L->n_chunks <= 0 || !(num_data > 0)) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  if (L->dtype == SGMCMC_F32)
+    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob);
+  else
+    hipLaunchKernelGGL(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob);
+  if (calc_log_prob) {
+    hipLaunchKernelGGL(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
+    hipLaunchKernelGGL(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
+  }
   return (int)hipGetLastError();
 }
 

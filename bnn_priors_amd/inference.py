@@ -213,19 +213,25 @@ class SGLDRunner:
         if self.optimizer.engine.nonfinite_seen():
             raise ValueError("Potential is NaN")
 
-    def _model_potential_and_grad(self, x, y):
-        """zero grads, potential_avg forward/backward.  The +-grad_max clamp of
-        inference.py:219-220 happens inside the step kernel; the NaN test of :221 is
-        the deferred ``_check_finite``.  Returns device tensors (no sync)."""
-        self.optimizer.zero_grad()
-        loss, log_prior, potential, accs, _ = self.model.split_potential_and_acc(
-            x, y, self.eff_num_data)
-        potential.backward()
-        return loss, log_prior, potential, accs.mean()
+    def _potential(self):
+        try:
+            return self._potential_obj
+        except AttributeError:
+            from .potential import Potential
+            self._potential_obj = Potential(self.model, self.optimizer, self.eff_num_data)
+            return self._potential_obj
+
+    def _model_potential_and_grad(self, x, y, want_metrics=True):
+        """zero grads, g <- grad potential_avg(x, y) (inference.py:215-223).  The likelihood goes
+        through autograd, element-wise priors through one fused launch (potential.py).  The
+        +-grad_max clamp of :219-220 happens inside the step kernel; the NaN test of :221 is the
+        deferred ``_check_finite``.  Returns device tensors (no sync); log_prior, potential and
+        acc are None unless ``want_metrics``."""
+        return self._potential().minibatch(x, y, want_metrics)
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
         "inference.py:225-249"
-        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store_metrics)
         self.optimizer.step(calc_metrics=store_metrics)
         lr = self.optimizer.param_groups[0]["lr"]
         if lr_decay:
@@ -281,7 +287,9 @@ class VerletSGLDRunner(SGLDRunner):
                                **self._sampler_kwargs())
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
-        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
+        # an M-H point or the very first step always stores metrics (see below)
+        want = store_metrics or i == 0 or initial_step
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, want)
         lr = self.optimizer.param_groups[0]["lr"]
         opt, is_hmc = self.optimizer, _is_hmc(self.optimizer)
         rejected = delta_energy = None

@@ -28,24 +28,15 @@ class VerletSGLDRunnerReject(SGLDRunner):
                                **self._sampler_kwargs())
 
     def _exact_model_potential_and_grad(self, batches):
-        """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N], accumulated by
-        autograd over the whole loader (inference_reject.py:18-33)."""
-        self.optimizer.zero_grad()
-        log_prior = self.model.log_prior()
-        log_norm_prior = log_prior / -self.eff_num_data
-        log_norm_prior.backward()
-        loss = 0.
-        for x, y in batches:
-            this_loss = self.model.log_likelihood(x, y, -x.size(0) / self.eff_num_data)
-            this_loss.backward()
-            loss = loss + this_loss.detach()
-        return loss, log_prior.detach(), loss + log_norm_prior.detach()
+        """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N], accumulated over the
+        whole loader (inference_reject.py:18-33); see potential.py."""
+        return self._potential().exact(batches)
 
     def leapfrog(self, step, x, y, last_of_epoch):
         """One minibatch leapfrog step: stochastic gradient, fused sampler transition,
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
-        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y)
         store = (step % self.metrics_skip) == 0
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
         self.optimizer.step(calc_metrics=store)
         if store:
             self._check_finite()
@@ -57,6 +48,8 @@ class VerletSGLDRunnerReject(SGLDRunner):
                                total_energy=self._total_energy + delta_energy)
         if not last_of_epoch:   # the last scheduler step of an epoch follows final_step
             self.scheduler.step()
+        elif acc is None:       # the sample row logs the last minibatch's accuracy (quirk 5)
+            acc = self._potential().accuracy(x, y) if self._potential().fast else acc
         return acc
 
     def begin(self):

@@ -286,6 +286,17 @@ class Engine:
         self._touch()
         return self.fetch_state()[:, _hip.SEG_STATE_FIELDS.index("aux")].copy()
 
+    def prior_grad(self, num_data, calc_log_prob):
+        _hip.check(self.lib.sgmcmc_prior_grad(ctypes.byref(self.layout), float(num_data),
+                                              int(bool(calc_log_prob)), 0, self.stream()),
+                   "sgmcmc_prior_grad")
+        if calc_log_prob:
+            self._touch()
+
+    def log_prior_total(self):
+        "sum of the fused priors' log-densities from the last prior_grad(calc_log_prob=True)"
+        return self.scalars[2]
+
     def nonfinite_seen(self, reset=True):
         flag = self.scalars[1].item() != 0.0
         if flag and reset:

@@ -110,6 +110,40 @@ class SGLD(torch.optim.Optimizer):
             eng.step(gi, kind, flags, draw, grad_clamp=self.grad_clamp, **sc)
         self._check_nan()
 
+    # ------------------------------------------------------------------ fused priors
+    def fuse_priors(self, model):
+        """Let the engine differentiate the element-wise priors of ``model`` in one kernel
+        (``add_prior_gradient``) instead of autograd.  Returns the Prior modules that can NOT be
+        fused (tensor-valued or learnable loc/scale, other families): their ``log_prob`` must stay
+        in the autograd potential.  Parameters without a prior (e.g. BatchNorm) get none."""
+        from ..prior import named_priors
+        by_param = {id(pr.p): pr for _, pr in named_priors(model)}
+        specs, leftover = [], []
+        for p in self._engine.params:
+            pr = by_param.pop(id(p), None)
+            sp = pr.fused_spec() if pr is not None else None
+            if pr is not None and sp is None:
+                leftover.append(pr)
+            specs.append(sp)
+        leftover.extend(by_param.values())   # priors whose .p this optimizer does not own
+        self._engine.set_priors(specs)
+        self._fused_any = any(sp is not None for sp in specs)
+        return leftover
+
+    @torch.no_grad()
+    def add_prior_gradient(self, calc_log_prior=False):
+        """p.grad += d/dtheta[-log p(theta)/N] for every fused prior (one launch); with
+        ``calc_log_prior`` the summed log-density is left on the device (``fused_log_prior()``)."""
+        eng = self._engine
+        eng.refresh(self._preconditioners(), raise_on_no_grad=True)
+        nd = self.param_groups[0]['num_data']
+        assert all(g['num_data'] == nd for g in self.param_groups), "unclear which `num_data` to use"
+        eng.prior_grad(nd, calc_log_prior)
+
+    def fused_log_prior(self):
+        "0-d float64 device tensor: log-density of the fused priors at the last add_prior_gradient"
+        return self._engine.log_prior_total()
+
     # ------------------------------------------------------------------ reference API
     def delta_energy(self, a, b) -> float:
         return math.inf  # sgld.py:54-55

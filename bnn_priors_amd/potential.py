@@ -1,0 +1,97 @@
+"""Gradient of the average potential, split the way the engine wants it.
+
+    potential_avg(x, y) = -(1/B) sum_i log p(y_i | x_i, theta) - log p(theta) / N
+                                                        (reference: models/base.py:72-77)
+
+The reference sends both terms through autograd and ``torch.distributions`` (about ten
+ATen launches and two validation syncs per prior tensor per step).  Here
+
+* the likelihood term goes through autograd as one ``cross_entropy`` on the network's
+  logits (same value as ``Categorical(logits=f).log_prob(y)``, models/base.py:181-182),
+* element-wise priors with scalar loc/scale are differentiated by ONE fused HIP launch
+  (``optimizer.add_prior_gradient``) that also leaves the summed log-density on the device,
+* anything else (other prior families, tensor-valued scales, non-classification models)
+  falls back to the reference's formulation unchanged.
+
+Nothing here synchronises with the host; callers ``.item()`` what they log.
+"""
+import torch
+import torch.nn.functional as F
+
+from .models.base import ClassificationModel
+
+
+class Potential:
+    def __init__(self, model, optimizer, num_data):
+        self.model, self.opt, self.N = model, optimizer, float(num_data)
+        self.fast = (isinstance(model, ClassificationModel)
+                     and isinstance(model.softmax_temp, (int, float))
+                     and hasattr(optimizer, "fuse_priors"))
+        self.leftover = optimizer.fuse_priors(model) if self.fast else None
+
+    # ------------------------------------------------------------------ pieces
+    def _logits(self, x):
+        f = self.model.net(x)
+        return f if self.model.softmax_temp == 1 else f / self.model.softmax_temp
+
+    def _leftover_log_prior(self):
+        if not self.leftover:
+            return None
+        return sum(pr.log_prob() for pr in self.leftover)
+
+    def _log_prior(self, leftover_lp):
+        lp = self.opt.fused_log_prior()          # float64, on the device
+        return lp if leftover_lp is None else lp + leftover_lp.detach().double()
+
+    # ------------------------------------------------------------------ minibatch gradient
+    def minibatch(self, x, y, want_metrics):
+        """zero grads; g <- grad potential_avg(x, y).  Returns (loss, log_prior, potential, acc)
+        as device tensors; log_prior / potential / acc are None unless ``want_metrics``."""
+        self.opt.zero_grad()
+        if not self.fast:
+            loss, log_prior, potential, accs, _ = self.model.split_potential_and_acc(x, y, self.N)
+            potential.backward()
+            return loss, log_prior, potential, accs.mean()
+        f = self._logits(x)
+        loss = F.cross_entropy(f, y)
+        extra = self._leftover_log_prior()
+        (loss if extra is None else loss - extra / self.N).backward()
+        self.opt.add_prior_gradient(calc_log_prior=want_metrics)
+        if not want_metrics:
+            return loss.detach(), None, None, None
+        with torch.no_grad():
+            log_prior = self._log_prior(extra)
+            potential = loss.detach().double() - log_prior / self.N
+            acc = f.argmax(dim=1).eq(y).float().mean()
+        return loss.detach(), log_prior, potential, acc
+
+    def accuracy(self, x, y):
+        with torch.no_grad():
+            return self._logits(x).argmax(dim=1).eq(y).float().mean()
+
+    # ------------------------------------------------------------------ full-data gradient
+    def exact(self, batches):
+        """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N]
+        (reference: inference_reject.py:18-33).  Returns (loss, log_prior, potential)."""
+        self.opt.zero_grad()
+        if not self.fast:
+            log_prior = self.model.log_prior()
+            lnp = log_prior / -self.N
+            lnp.backward()
+            loss = 0.
+            for x, y in batches:
+                this = self.model.log_likelihood(x, y, -x.size(0) / self.N)
+                this.backward()
+                loss = loss + this.detach()
+            return loss, log_prior.detach(), loss + lnp.detach()
+        loss = torch.zeros((), dtype=torch.float64, device=self.opt.engine.device)
+        for x, y in batches:
+            this = F.cross_entropy(self._logits(x), y, reduction="sum") / self.N
+            this.backward()
+            loss = loss + this.detach().double()
+        extra = self._leftover_log_prior()
+        if extra is not None:
+            (extra / -self.N).backward()
+        self.opt.add_prior_gradient(calc_log_prior=True)
+        log_prior = self._log_prior(extra)
+        return loss, log_prior, loss - log_prior / self.N

@@ -162,6 +162,15 @@ int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, doubl
  * (mcmc/sgld.py:156-179); the host finishes (mean + eps, min, ^(-1/4)). */
 int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* stream);
 
+/* g <- g - (1/N) dlog p(theta)/dtheta for every segment with prior_kind != NONE
+ * (element-wise Normal / Laplace / Student-t with scalar loc, scale, df), i.e. what
+ * autograd adds for the "- log_prior / N" term of potential_avg (models/base.py:72-77,
+ * prior/base.py:57-58, prior/loc_scale.py:34-35,66-67,74-77).  With calc_log_prob != 0 also
+ * state[s].aux <- sum_j log p(theta_j) (fp64) and scalars[2] <- the total over segments.
+ * One launch for all tensors instead of ~10 ATen launches per prior tensor per step. */
+int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob, uint32_t flags,
+                      void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

@@ -74,8 +74,8 @@ def _with_oracle_sampler(base):
                           momentum=self.momentum, temperature=self.temperature, noise=noise)
             return opt
 
-        def _model_potential_and_grad(self, x, y):
-            out = super()._model_potential_and_grad(x, y)
+        def _model_potential_and_grad(self, x, y, want_metrics=True):
+            out = super()._model_potential_and_grad(x, y, want_metrics)
             for p in self.optimizer.param_groups[0]["params"]:     # inference.py:219-220
                 p.grad.clamp_(min=-self.grad_max, max=self.grad_max)
             return out
