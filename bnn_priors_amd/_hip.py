@@ -67,6 +67,8 @@ EXPORTS = {
     "sgmcmc_step": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs), ctypes.c_void_p]),
     "sgmcmc_step_timed": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_step_indirect": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sgmcmc_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "sgmcmc_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,

@@ -230,7 +230,7 @@ __device__ __forceinline__ void update_elem(const Coef<T, KIND>& C, T xi, T gi, 
 }
 
 template <typename T, int KIND, bool VEC>
-__global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+__device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
   const int64_t chunk = A.chunk_begin + blockIdx.x;
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
@@ -336,6 +336,18 @@ __global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_
   block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_NSUMS);
 }
 
+template <typename T, int KIND, bool VEC>
+__global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  step_body<T, KIND, VEC>(L, A);
+}
+// scalars fetched from device memory at run time (graph replay)
+template <typename T, int KIND, bool VEC>
+__global__ __launch_bounds__(kThreads) void step_kernel_indirect(sgmcmc_layout L,
+                                                                 const sgmcmc_step_args* Ap) {
+  const sgmcmc_step_args A = *Ap;
+  step_body<T, KIND, VEC>(L, A);
+}
+
 // ------------------------------------------------------------------ per-segment finalize
 // Sums a segment's chunk partials in a fixed order (thread t takes chunks t, t+256, ...;
 // then a fixed LDS tree) and applies the reference's scalar bookkeeping.
@@ -368,7 +380,7 @@ __device__ __forceinline__ int64_t seg_chunks(const sgmcmc_segment& s) {
   return (s.numel + SGMCMC_CHUNK - 1) / SGMCMC_CHUNK;
 }
 
-__global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+__device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
   const int seg = A.seg_begin + blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[SGMCMC_NSUMS];
@@ -407,6 +419,15 @@ __global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L
   }
   // non-finite gradient detector (raise_on_nan, sgld.py:101-104): sum g^2 is finite iff all g are
   if (!(S[0] - S[0] == 0.0)) L.scalars[1] = 1.0;
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  finalize_step_body(L, A);
+}
+__global__ __launch_bounds__(kThreads) void finalize_step_kernel_indirect(sgmcmc_layout L,
+                                                                          const sgmcmc_step_args* Ap) {
+  const sgmcmc_step_args A = *Ap;
+  finalize_step_body(L, A);
 }
 
 // ------------------------------------------------------------------ auxiliary kernels
@@ -603,6 +624,17 @@ void launch_step_kind(const sgmcmc_layout& L, const sgmcmc_step_args& A, hipStre
   }
 }
 
+template <typename T, bool VEC>
+void launch_step_kind_indirect(const sgmcmc_layout& L, const sgmcmc_step_args& A,
+                               const sgmcmc_step_args* Ad, hipStream_t s) {
+  const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
+  switch (A.kind) {
+    case SGMCMC_VERLET: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_VERLET, VEC>), grid, block, 0, s, L, Ad); break;
+    case SGMCMC_HMC: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_HMC, VEC>), grid, block, 0, s, L, Ad); break;
+    default: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_SGLD, VEC>), grid, block, 0, s, L, Ad); break;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -634,6 +666,27 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
 
 int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
   return sgmcmc_step_timed(L, A, stream, nullptr, nullptr);
+}
+
+int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
+                         void* stream) {
+  if (!L || !A || !Ad || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
+    return (int)hipErrorInvalidValue;
+  if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = !(A->flags & SGMCMC_UNALIGNED);
+  if (L->dtype == SGMCMC_F32) {
+    if (vec) launch_step_kind_indirect<float, true>(*L, *A, Ad, s);
+    else launch_step_kind_indirect<float, false>(*L, *A, Ad, s);
+  } else if (L->dtype == SGMCMC_F64) {
+    if (vec) launch_step_kind_indirect<double, true>(*L, *A, Ad, s);
+    else launch_step_kind_indirect<double, false>(*L, *A, Ad, s);
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(finalize_step_kernel_indirect, dim3((unsigned)(A->seg_end - A->seg_begin)),
+                     dim3(kThreads), 0, s, *L, Ad);
+  return (int)hipGetLastError();
 }
 
 int sgmcmc_event_create(void** ev) {

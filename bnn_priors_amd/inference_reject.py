@@ -15,12 +15,16 @@ __all__ = ("VerletSGLDRunnerReject", "HMCRunnerReject", "SGLDRunnerReject")
 
 
 class VerletSGLDRunnerReject(SGLDRunner):
-    def __init__(self, *a, cycle_seed=None, **kw):
+    def __init__(self, *a, cycle_seed=None, use_graph=True, **kw):
         """``cycle_seed``: None reproduces the reference (a fresh non-deterministic
         shuffle seed per cycle, inference_reject.py:72); an int pins cycle c's seed to
-        ``cycle_seed + c`` so that runs (and parity tests) are repeatable."""
+        ``cycle_seed + c`` so that runs (and parity tests) are repeatable.
+        ``use_graph``: replay ordinary leapfrog steps from a captured hipGraph (graphed.py)
+        when the model allows it; results are identical to the eager path."""
         super().__init__(*a, **kw)
         self.cycle_seed = cycle_seed
+        self.use_graph = use_graph
+        self._graphed = None
 
     def _make_optimizer(self, params):
         return mcmc.VerletSGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
@@ -36,6 +40,12 @@ class VerletSGLDRunnerReject(SGLDRunner):
         """One minibatch leapfrog step: stochastic gradient, fused sampler transition,
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
         store = (step % self.metrics_skip) == 0
+        if not store and self._graph_for(x, y) is not None:
+            self._graphed.replay(x, y)
+            if not last_of_epoch:
+                self.scheduler.step()
+                return None
+            return self._potential().accuracy(x, y)          # quirk 5: sample row logs it
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
         self.optimizer.step(calc_metrics=store)
         if store:
@@ -51,6 +61,19 @@ class VerletSGLDRunnerReject(SGLDRunner):
         elif acc is None:       # the sample row logs the last minibatch's accuracy (quirk 5)
             acc = self._potential().accuracy(x, y) if self._potential().fast else acc
         return acc
+
+    def _graph_for(self, x, y):
+        """the captured graph if this step can use it (fused potential, matching batch shape)"""
+        if not self.use_graph or self._graphed is False:
+            return None
+        if self._graphed is None:
+            pot = self._potential()
+            if not pot.fast or pot.leftover or len(self.optimizer.param_groups) != 1:
+                self._graphed = False
+                return None
+            from .graphed import GraphedLeapfrog
+            self._graphed = GraphedLeapfrog(pot, self.optimizer, x, y)
+        return self._graphed if self._graphed.matches(x, y) else None
 
     def begin(self):
         """optimizer, scheduler, exact initial gradient, momentum draw and the first

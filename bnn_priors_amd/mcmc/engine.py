@@ -144,7 +144,7 @@ class Engine:
     def stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def refresh(self, preconditioners, need_grad=True, raise_on_no_grad=True):
+    def refresh(self, preconditioners, need_grad=True, raise_on_no_grad=True, defer_upload=False):
         """Bring the device segment table up to date with the parameters' current
         storage, their gradients' storage and the preconditioners."""
         ptrs = []
@@ -177,7 +177,7 @@ class Engine:
             if M[i] != m:
                 M[i] = m
                 self._seg_dirty = True
-        if self._seg_dirty:
+        if self._seg_dirty and not defer_upload:   # deferred: during hipGraph capture
             self._upload_segments()
 
     def _upload_segments(self):
@@ -213,16 +213,27 @@ class Engine:
     def _touch(self):
         self._state_host = None
 
-    def step(self, gi, kind, flags, draw, *, num_data, b2h2, bh, bhn, mom_decay, grad_v, noise_std,
-             rmsprop_alpha, grad_clamp=0.0):
+    def make_args(self, gi, kind, flags, draw, *, num_data, b2h2, bh, bhn, mom_decay, grad_v,
+                  noise_std, rmsprop_alpha, grad_clamp=0.0):
         s0, s1, c0, c1 = self.group_ranges[gi]
+        return _hip.StepArgs(kind=kind, flags=flags | (_hip.UNALIGNED if self._unaligned else 0),
+                             seg_begin=s0, seg_end=s1, chunk_begin=c0, chunk_end=c1,
+                             num_data=num_data, b2h2=b2h2, bh=bh, bhn=bhn, mom_decay=mom_decay,
+                             grad_v=grad_v, noise_std=noise_std, rmsprop_alpha=rmsprop_alpha,
+                             grad_clamp=grad_clamp, seed=self.seed, draw=draw, stream=self.chain_id)
+
+    def step_indirect(self, A_host, args_dev_ptr):
+        "enqueue the fused transition with its scalars read from device memory (graph capture)"
+        _hip.check(self.lib.sgmcmc_step_indirect(ctypes.byref(self.layout), ctypes.byref(A_host),
+                                                 ctypes.c_void_p(args_dev_ptr), self.stream()),
+                   "sgmcmc_step_indirect")
+        self._touch()
+
+    def step(self, gi, kind, flags, draw, **scalars):
         if flags & _hip.SAVE_STATE:
             self.ensure_prev()
-        A = _hip.StepArgs(kind=kind, flags=flags | (_hip.UNALIGNED if self._unaligned else 0),
-                          seg_begin=s0, seg_end=s1, chunk_begin=c0, chunk_end=c1,
-                          num_data=num_data, b2h2=b2h2, bh=bh, bhn=bhn, mom_decay=mom_decay,
-                          grad_v=grad_v, noise_std=noise_std, rmsprop_alpha=rmsprop_alpha,
-                          grad_clamp=grad_clamp, seed=self.seed, draw=draw, stream=self.chain_id)
+        A = self.make_args(gi, kind, flags, draw, **scalars)
+        c0, c1 = A.chunk_begin, A.chunk_end
         if self.kernel_timing:
             e0, e1 = self._event_pair()
             _hip.check(self.lib.sgmcmc_step_timed(ctypes.byref(self.layout), ctypes.byref(A),

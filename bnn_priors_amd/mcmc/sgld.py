@@ -173,6 +173,14 @@ class SGLD(torch.optim.Optimizer):
                     noise_std=g['noise_std'] if g['temperature'] > 0 else 0.0,
                     rmsprop_alpha=g['rmsprop_alpha'])
 
+    def _plain_step_spec(self, calc_metrics):
+        """(kind, flags, scalars) of an ordinary ``step`` with the CURRENT lr / temperature --
+        used by graphed.py to parameterise a replay without launching anything."""
+        g = self.param_groups[0]
+        has_mom = g['momentum'] > 0
+        flags = (_hip.CALC_METRICS if calc_metrics else 0) | (0 if has_mom else _hip.NO_MOMENTUM)
+        return _hip.SGLD, flags, self._sgld_scalars(g)
+
     def _sgld_transition(self, closure, calc_metrics, is_final):
         loss = self._run_closure(closure)
         moms = {g['momentum'] > 0 for g in self.param_groups}

@@ -39,6 +39,11 @@ class VerletSGLD(SGLD):
                     mom_decay=g['mom_decay'], grad_v=g['grad_v'], noise_std=g['noise_std'],
                     rmsprop_alpha=g['rmsprop_alpha'])
 
+    def _plain_step_spec(self, calc_metrics):
+        g = self.param_groups[0]
+        self._update_group_fn(g)
+        return self._KIND, (_hip.CALC_METRICS if calc_metrics else 0), self._args_of(g)
+
     def _transition(self, closure, flags, group_fn):
         loss = self._run_closure(closure)
 

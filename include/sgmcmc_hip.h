@@ -137,6 +137,13 @@ int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream)
  * hipEvent_t created by sgmcmc_event_create. */
 int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
                       void* ev_start, void* ev_stop);
+/* As sgmcmc_step, but the kernels read the transition's scalars from DEVICE memory
+ * (*A_dev, same struct) when they run.  Launch geometry and kernel selection (kind, dtype,
+ * seg/chunk ranges, SGMCMC_UNALIGNED, SGMCMC_NO_MOMENTUM) are taken from *A_host and must not
+ * differ in *A_dev.  This is what makes the launch capturable in a hipGraph that is replayed
+ * with a different learning rate / draw counter / flags every step. */
+int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A_host,
+                         const sgmcmc_step_args* A_dev, void* stream);
 int sgmcmc_event_create(void** ev);
 int sgmcmc_event_destroy(void* ev);
 int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */

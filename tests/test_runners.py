@@ -124,3 +124,33 @@ def test_runner_on_gpu_matches_reference_goldens(name):
     # ~8e-3 of delta_energy (inherent to the reference's formula); the
     # GPU's GEMM / reduction order differs from the CPU's, so allow a few of those.
     _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128)
+
+
+@pytest.mark.gpu
+def test_graph_replay_is_bit_identical_to_eager():
+    "hipGraph replay of ordinary steps changes nothing: same metric streams, same samples, same bits"
+    outs = []
+    for use_graph in (False, True):
+        cfg = RC.CASES["VerletSGLDReject"]
+        dev = "cuda:0"
+        train, test, (x, y) = RC.make_data(dev)
+        model = RC.make_net(models, x, y, device=dev)
+        metrics = MemoryMetrics()
+        torch.manual_seed(RC.SEED)
+        runner = inference_reject.VerletSGLDRunnerReject(
+            model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+            temperature=cfg["temperature"], momentum=cfg["momentum"], reject_samples=True,
+            metrics_saver=metrics, model_saver=None, seed=RC.SEED, chain_id=0,
+            cycle_seed=RC.CYCLE_SEED, use_graph=use_graph, **RC.RUN_KW)
+        runner.run()
+        assert (runner._graphed not in (None, False)) == use_graph
+        outs.append((RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}))
+    (s0, p0), (s1, p1) = outs
+    assert sorted(s0) == sorted(s1)
+    for k in s0:
+        if k in ("timestamps",):
+            continue
+        assert np.array_equal(s0[k][0], s1[k][0]), k
+        assert np.array_equal(s0[k][1], s1[k][1]), (k, s0[k][1], s1[k][1])
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
