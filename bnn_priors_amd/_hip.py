@@ -22,7 +22,7 @@ CHUNK = 4096
 NSUMS = 6
 F32, F64 = 0, 1
 VERLET, HMC, SGLD = 0, 1, 2
-INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM = 1, 2, 4, 8, 16, 32
+INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM, SMALL_FINALIZE = 1, 2, 4, 8, 16, 32, 64
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T = 0, 1, 2, 3
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",

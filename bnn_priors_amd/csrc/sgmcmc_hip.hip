@@ -380,22 +380,23 @@ __device__ __forceinline__ int64_t seg_chunks(const sgmcmc_segment& s) {
   return (s.numel + SGMCMC_CHUNK - 1) / SGMCMC_CHUNK;
 }
 
-__device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
-  const int seg = A.seg_begin + blockIdx.x;
-  const sgmcmc_segment s = L.segs[seg];
-  double S[SGMCMC_NSUMS];
-  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
-  if (threadIdx.x != 0) return;
+// Scalar bookkeeping of one segment after its six sums S are known (thread-serial).
+// Returns the segment's contribution to delta_energy's loop: state.delta_energy + point energy
+// evaluated with THIS transition's gradient / momentum (verlet_sgld.py:32-47, hmc.py:32-33).
+__device__ __forceinline__ double segment_bookkeeping(const sgmcmc_layout& L, const sgmcmc_step_args& A,
+                                                      int seg, const sgmcmc_segment& s,
+                                                      const double (&S)[SGMCMC_NSUMS]) {
   sgmcmc_seg_state* st = &L.state[seg];
 #pragma unroll
   for (int k = 0; k < SGMCMC_NSUMS; ++k) st->sums[k] = S[k];
   const double d = (double)s.numel, M = s.M;
   const bool initial = A.flags & SGMCMC_INITIAL, final_ = A.flags & SGMCMC_FINAL;
+  double point = 0.0;
   if (A.kind == SGMCMC_VERLET) {
     const double c_gm = -.5 * A.bhn * M;  // verlet_sgld.py:170
+    const double curv = M * M * (A.num_data * A.num_data) * A.b2h2 / 8;  // :44-47
     if (initial) {
-      const double curv = M * M * (A.num_data * A.num_data) * A.b2h2 / 8;  // :44-47
-      st->delta_energy = -(curv * S[0]);                                    // :172
+      st->delta_energy = -(curv * S[0]);   // :172
     } else {
       st->delta_energy += st->prev_delta;  // :174
       st->delta_energy += c_gm * S[1];     // :175
@@ -405,20 +406,65 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
       st->est_temperature = (final_ ? S[4] : S[3]) / d;  // :181-187
       st->est_config_temp = S[5] * (A.num_data / d);     // :189
     }
+    point = curv * S[0];
   } else if (A.kind == SGMCMC_HMC) {
     if (initial) st->delta_energy = -.5 * S[3];  // hmc.py:49-51
     if (A.flags & SGMCMC_CALC_METRICS) {
       st->est_temperature = (final_ ? S[4] : S[3]) / d;  // hmc.py:52-53,59,71
       st->est_config_temp = S[5] * (A.num_data / d);     // hmc.py:61
     }
+    point = .5 * S[4];  // kinetic energy of the momentum this transition left behind
   } else {
     if (A.flags & SGMCMC_CALC_METRICS) {
       st->est_temperature = S[3] / d;                 // sgld.py:127-137
       st->est_config_temp = S[5] * (A.num_data / d);  // sgld.py:146
     }
   }
+  st->point_energy = point;
   // non-finite gradient detector (raise_on_nan, sgld.py:101-104): sum g^2 is finite iff all g are
   if (!(S[0] - S[0] == 0.0)) L.scalars[1] = 1.0;
+  return st->delta_energy + point;
+}
+
+__device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
+  const int seg = A.seg_begin + blockIdx.x;
+  const sgmcmc_segment s = L.segs[seg];
+  double S[SGMCMC_NSUMS];
+  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  if (threadIdx.x != 0) return;
+  segment_bookkeeping(L, A, seg, s, S);
+}
+
+// Small models (few chunks): ONE workgroup finalizes every segment -- thread t owns segments
+// t, t+256, ... and sums their chunk partials serially in chunk order -- and also leaves
+// scalars[3] = sum_s (delta_energy_s + point_energy_s) in segment order, i.e. the loop of
+// VerletSGLD.delta_energy for the gradient this transition used, so a metric step needs no
+// further reduction launches.
+__device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
+  __shared__ double terms[kThreads];
+  double total = 0.0;
+  for (int base = A.seg_begin; base < A.seg_end; base += kThreads) {
+    const int seg = base + (int)threadIdx.x;
+    double term = 0.0;
+    if (seg < A.seg_end) {
+      const sgmcmc_segment s = L.segs[seg];
+      double S[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
+      const int64_t n = seg_chunks(s);
+      for (int64_t c = 0; c < n; ++c) {
+#pragma unroll
+        for (int k = 0; k < SGMCMC_NSUMS; ++k) S[k] += L.partials[(s.first_chunk + c) * SGMCMC_NSUMS + k];
+      }
+      term = segment_bookkeeping(L, A, seg, s, S);
+    }
+    terms[threadIdx.x] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = A.seg_end - base < kThreads ? A.seg_end - base : kThreads;
+      for (int i = 0; i < m; ++i) total += terms[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) L.scalars[3] = total;
 }
 
 __global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
@@ -428,6 +474,15 @@ __global__ __launch_bounds__(kThreads) void finalize_step_kernel_indirect(sgmcmc
                                                                           const sgmcmc_step_args* Ap) {
   const sgmcmc_step_args A = *Ap;
   finalize_step_body(L, A);
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_small_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  finalize_small_body(L, A);
+}
+__global__ __launch_bounds__(kThreads) void finalize_small_kernel_indirect(sgmcmc_layout L,
+                                                                           const sgmcmc_step_args* Ap) {
+  const sgmcmc_step_args A = *Ap;
+  finalize_small_body(L, A);
 }
 
 // ------------------------------------------------------------------ auxiliary kernels
@@ -659,8 +714,11 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
     return (int)hipErrorInvalidValue;
   }
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, s);
-  hipLaunchKernelGGL(finalize_step_kernel, dim3((unsigned)(A->seg_end - A->seg_begin)),
-                     dim3(kThreads), 0, s, *L, *A);
+  if (A->flags & SGMCMC_SMALL_FINALIZE)
+    hipLaunchKernelGGL(finalize_small_kernel, dim3(1), dim3(kThreads), 0, s, *L, *A);
+  else
+    hipLaunchKernelGGL(finalize_step_kernel, dim3((unsigned)(A->seg_end - A->seg_begin)),
+                       dim3(kThreads), 0, s, *L, *A);
   return (int)hipGetLastError();
 }
 
@@ -684,8 +742,11 @@ int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A, cons
   } else {
     return (int)hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(finalize_step_kernel_indirect, dim3((unsigned)(A->seg_end - A->seg_begin)),
-                     dim3(kThreads), 0, s, *L, Ad);
+  if (A->flags & SGMCMC_SMALL_FINALIZE)
+    hipLaunchKernelGGL(finalize_small_kernel_indirect, dim3(1), dim3(kThreads), 0, s, *L, Ad);
+  else
+    hipLaunchKernelGGL(finalize_step_kernel_indirect, dim3((unsigned)(A->seg_end - A->seg_begin)),
+                       dim3(kThreads), 0, s, *L, Ad);
   return (int)hipGetLastError();
 }
 

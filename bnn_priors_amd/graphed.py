@@ -14,9 +14,12 @@ learning-rate-derived scalars, the Philox draw counter -- lives in a device-resi
 small ring of pinned slots before each replay, so a replay can never observe the next
 step's scalars.
 
-Steps that read metrics back (every ``metrics_skip``-th), M-H points and off-shape batches
-keep using the eager path; ``p.grad`` is re-bound to the graph's static gradient tensors
-whenever control returns to the graph.
+Two graphs are captured: the plain step and the metric step (every ``metrics_skip``-th), which
+additionally evaluates the accuracy and the fused log-prior and packs everything the runner
+logs -- loss, acc, log-prior, the transition's energy total, the per-segment temperature
+estimates -- into one buffer that is read back with a single copy.  M-H points and off-shape
+batches keep using the eager path; ``p.grad`` is re-bound to the replayed graph's static
+gradient tensors whenever control moves between paths.
 """
 import ctypes
 
@@ -63,14 +66,23 @@ class GraphedLeapfrog:
                                   grad_clamp=self.opt.grad_clamp, **sc)
 
     # ------------------------------------------------------------------ capture
-    def _body(self, capturing):
+    N_HEAD = 6   # packed read-back: loss, acc, scalars[0..3], then the per-segment state array
+
+    def _body(self, capturing, metrics):
         self.opt.zero_grad()
-        loss = F.cross_entropy(self.pot._logits(self.x), self.y)
+        f = self.pot._logits(self.x)
+        loss = F.cross_entropy(f, self.y)
         loss.backward()
         self.eng.refresh(self.opt._preconditioners(), defer_upload=capturing)
-        self.eng.prior_grad(self.pot.N, False)
+        self.eng.prior_grad(self.pot.N, metrics)
         self.eng.step_indirect(self._A_host, self.args_dev.data_ptr())
-        return loss.detach()
+        if not metrics:
+            return loss.detach(), None
+        with torch.no_grad():
+            acc = f.argmax(dim=1).eq(self.y).double().mean()
+            packed = torch.cat([loss.detach().double().view(1), acc.view(1), self.eng.scalars[:4],
+                                self.eng.state_dev])
+        return loss.detach(), packed
 
     def _snapshot(self):
         eng = self.eng
@@ -91,43 +103,65 @@ class GraphedLeapfrog:
         eng._touch()
 
     def _capture(self, x, y, warmup):
+        dev = self.eng.device
         self.x.copy_(x)
         self.y.copy_(y)
         snap = self._snapshot()
         self._A_host = self._args()
         self._push_args(self._A_host)
-        side = torch.cuda.Stream(device=self.eng.device)
-        side.wait_stream(torch.cuda.current_stream(self.eng.device))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._body(False)
-        torch.cuda.current_stream(self.eng.device).wait_stream(side)
-        torch.cuda.synchronize(self.eng.device)
+                self._body(False, False)
+                self._body(False, True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
         self._restore(snap)
-        self.opt.zero_grad()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._body(True)
-        self.static_grads = [p.grad for p in self.eng.params]
-        self.eng.refresh(self.opt._preconditioners())      # upload the captured pointers
-        torch.cuda.synchronize(self.eng.device)
+        self.graphs, self.static_grads, self.outputs = {}, {}, {}
+        for metrics in (False, True):
+            self.opt.zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.outputs[metrics] = self._body(True, metrics)
+            self.graphs[metrics] = g
+            self.static_grads[metrics] = [p.grad for p in self.eng.params]
+        self._host_packed = torch.empty(self.outputs[True][1].shape, dtype=torch.float64).pin_memory()
+        self._bound = None
+        torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ replay
     def matches(self, x, y):
         return (tuple(x.shape), tuple(y.shape)) == self.shape
 
-    def replay(self, x, y):
-        """one ordinary leapfrog step (no metric read-back); returns the loss tensor (valid
-        until the next replay)"""
+    def replay(self, x, y, metrics=False):
+        """One leapfrog step.  ``metrics=False``: nothing is read back, returns None.
+        ``metrics=True``: the transition also updates the temperature estimates and the fused
+        log-prior; returns dict(loss, acc, log_prior, energy, nonfinite) of Python floats after ONE
+        device->host copy, and primes the engine's per-segment state cache with the same copy."""
         self.x.copy_(x)
         self.y.copy_(y)
-        params = self.eng.params
-        if params[0].grad is not self.static_grads[0]:
-            for p, g in zip(params, self.static_grads):
+        eng = self.eng
+        if self._bound is not metrics:
+            for p, g in zip(eng.params, self.static_grads[metrics]):
                 p.grad = g
-        self.eng.refresh(self.opt._preconditioners())
-        self._push_args(self._args())
-        self.graph.replay()
-        self.eng._touch()
-        self.eng.energy_ready = True
-        return self.loss
+            self._bound = metrics
+        elif eng.params[0].grad is not self.static_grads[metrics][0]:
+            for p, g in zip(eng.params, self.static_grads[metrics]):
+                p.grad = g
+        eng.refresh(self.opt._preconditioners())
+        self._push_args(self._args(calc_metrics=metrics))
+        self.graphs[metrics].replay()
+        eng._touch()
+        eng.energy_ready = True
+        if not metrics:
+            return None
+        eng.metrics_ready = True
+        self._host_packed.copy_(self.outputs[True][1], non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        v = self._host_packed.numpy()
+        eng._state_host = v[self.N_HEAD:].reshape(eng.n_seg, -1).copy()
+        if v[3] != 0.0:
+            eng.scalars[1].zero_()
+        return dict(loss=float(v[0]), acc=float(v[1]), nonfinite=bool(v[3] != 0.0),
+                    log_prior=float(v[4]), energy=float(v[5]))

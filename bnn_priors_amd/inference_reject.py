@@ -14,6 +14,11 @@ from .inference import SGLDRunner, _is_hmc
 __all__ = ("VerletSGLDRunnerReject", "HMCRunnerReject", "SGLDRunnerReject")
 
 
+def _f(v):
+    "python float of a number or 0-d tensor"
+    return v.item() if isinstance(v, torch.Tensor) else float(v)
+
+
 class VerletSGLDRunnerReject(SGLDRunner):
     def __init__(self, *a, cycle_seed=None, use_graph=True, **kw):
         """``cycle_seed``: None reproduces the reference (a fresh non-deterministic
@@ -40,27 +45,49 @@ class VerletSGLDRunnerReject(SGLDRunner):
         """One minibatch leapfrog step: stochastic gradient, fused sampler transition,
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
         store = (step % self.metrics_skip) == 0
-        if not store and self._graph_for(x, y) is not None:
-            self._graphed.replay(x, y)
+        opt, N = self.optimizer, self.eff_num_data
+        graphed = self._graph_for(x, y)
+        if graphed is not None:
+            r = graphed.replay(x, y, metrics=store)
+            acc = None
+            if store:
+                if r["nonfinite"]:
+                    raise ValueError("Potential is NaN")
+                potential = r["loss"] - r["log_prior"] / N
+                delta_energy = opt.delta_energy_from_total(r["energy"], self._initial_potential,
+                                                           potential)
+                self.store_metrics(i=step, loss=r["loss"], log_prior=r["log_prior"],
+                                   potential=potential, acc=r["acc"], lr=opt.param_groups[0]["lr"],
+                                   corresponds_to_sample=False, delta_energy=delta_energy,
+                                   total_energy=self._total_energy + delta_energy)
+                acc = r["acc"]
             if not last_of_epoch:
                 self.scheduler.step()
-                return None
-            return self._potential().accuracy(x, y)          # quirk 5: sample row logs it
+            elif acc is None:
+                acc = self._potential().accuracy(x, y)       # quirk 5: the sample row logs it
+            return acc
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
-        self.optimizer.step(calc_metrics=store)
+        opt.step(calc_metrics=store)
         if store:
             self._check_finite()
-            delta_energy = self.optimizer.delta_energy(self._initial_potential, potential)
+            delta_energy = self._delta_energy(potential)
             self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
                                potential=potential.item(), acc=acc.item(),
-                               lr=self.optimizer.param_groups[0]["lr"],
-                               corresponds_to_sample=False, delta_energy=delta_energy,
-                               total_energy=self._total_energy + delta_energy)
+                               lr=opt.param_groups[0]["lr"],
+                               corresponds_to_sample=False, delta_energy=_f(delta_energy),
+                               total_energy=self._total_energy + _f(delta_energy))
         if not last_of_epoch:   # the last scheduler step of an epoch follows final_step
             self.scheduler.step()
         elif acc is None:       # the sample row logs the last minibatch's accuracy (quirk 5)
             acc = self._potential().accuracy(x, y) if self._potential().fast else acc
         return acc
+
+    def _delta_energy(self, potential):
+        """energy difference since the last initial step, for the gradient the LAST transition
+        used (true at both call sites: right after ``step`` / ``final_step``) -- the fused launch
+        has already reduced it; samplers without that shortcut use ``delta_energy``"""
+        fn = getattr(self.optimizer, "delta_energy_of_last_transition", self.optimizer.delta_energy)
+        return fn(self._initial_potential, potential)
 
     def _graph_for(self, x, y):
         """the captured graph if this step can use it (fused potential, matching batch shape)"""
@@ -127,7 +154,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                         step += 1                                                    # quirk 6
                         loss, log_prior, potential = self._exact_model_potential_and_grad(batches)
                         opt.final_step(calc_metrics=True)
-                        delta_energy = opt.delta_energy(self._initial_potential, potential)
+                        delta_energy = _f(self._delta_energy(potential))
                         self._total_energy += delta_energy
                         self._initial_potential = potential.item()                   # quirk 1
                         rejected = False
@@ -135,7 +162,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                             rejected, _ = opt.maybe_reject(delta_energy)
                         self._check_finite()
                         self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
-                                           potential=potential.item(), acc=acc.item(),  # quirk 5
+                                           potential=potential.item(), acc=_f(acc),  # quirk 5
                                            lr=opt.param_groups[0]["lr"],
                                            corresponds_to_sample=True, delta_energy=delta_energy,
                                            total_energy=self._total_energy, rejected=rejected)

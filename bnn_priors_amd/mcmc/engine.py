@@ -108,6 +108,8 @@ class Engine:
         self.metrics_ready = False
         self.energy_ready = False
         self.hidden_keys = frozenset()   # state keys this sampler family does not have
+        # few chunks: one workgroup finalizes all segments and also emits the energy total
+        self.small_finalize = len(param_groups) == 1 and self.n_chunks <= 2048
 
     # ------------------------------------------------------------------ views
     def _view(self, arena, i):
@@ -216,6 +218,8 @@ class Engine:
     def make_args(self, gi, kind, flags, draw, *, num_data, b2h2, bh, bhn, mom_decay, grad_v,
                   noise_std, rmsprop_alpha, grad_clamp=0.0):
         s0, s1, c0, c1 = self.group_ranges[gi]
+        if self.small_finalize:
+            flags |= _hip.SMALL_FINALIZE
         return _hip.StepArgs(kind=kind, flags=flags | (_hip.UNALIGNED if self._unaligned else 0),
                              seg_begin=s0, seg_end=s1, chunk_begin=c0, chunk_end=c1,
                              num_data=num_data, b2h2=b2h2, bh=bh, bhn=bhn, mom_decay=mom_decay,
@@ -290,6 +294,10 @@ class Engine:
                                                 grad_clamp, 0, self.stream()), "sgmcmc_delta_energy")
         self._touch()
         return self.scalars[0].item()
+
+    def last_transition_energy(self):
+        "scalars[3]: sum_s(delta_energy_s + point_energy_s) left by the last small-finalize launch"
+        return self.scalars[3]
 
     def segment_sums(self, which):
         _hip.check(self.lib.sgmcmc_segment_sum(ctypes.byref(self.layout), which, 0, self.stream()),

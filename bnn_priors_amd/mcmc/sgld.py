@@ -148,6 +148,10 @@ class SGLD(torch.optim.Optimizer):
     def delta_energy(self, a, b) -> float:
         return math.inf  # sgld.py:54-55
 
+    def delta_energy_from_total(self, energy_total, prev_potential, potential):
+        "delta_energy given the fused launch's energy total (graphed.py); SGLD has none"
+        return math.inf
+
     @torch.no_grad()
     def sample_momentum(self, keep=0.0):
         "m <- sqrt(keep) m + sqrt(T (1-keep)) xi   (sgld.py:57-69)"

@@ -114,6 +114,26 @@ class VerletSGLD(SGLD):
             potential = potential.item()
         return total + (potential - prev_potential) * num_data
 
+    def delta_energy_from_total(self, energy_total, prev_potential, potential):
+        return energy_total + (potential - prev_potential) * self.param_groups[0]['num_data']
+
+    def delta_energy_of_last_transition(self, prev_potential, potential):
+        """``delta_energy`` when ``p.grad`` (HMC: the momentum) has not changed since the last
+        ``initial_step`` / ``step`` / ``final_step``: the fused launch already summed
+        ``state['delta_energy'] + _point_energy`` over the tensors, so no reduction is launched.
+        Falls back to ``delta_energy`` for big arenas.  ``potential`` may be device tensors; the
+        result is then a 0-d float64 device tensor (no sync)."""
+        eng = self._engine
+        if not eng.small_finalize:
+            return self.delta_energy(prev_potential, potential)
+        if not eng.energy_ready:
+            raise KeyError('delta_energy')
+        num_data = self.param_groups[0]['num_data']
+        total = eng.last_transition_energy()
+        if isinstance(potential, torch.Tensor) or isinstance(prev_potential, torch.Tensor):
+            return total + (potential - prev_potential) * num_data
+        return total.item() + (potential - prev_potential) * num_data
+
     @torch.no_grad()
     def maybe_reject(self, delta_energy):
         """Metropolis-Hastings test (verlet_sgld.py:49-70).  The uniform is the Philox

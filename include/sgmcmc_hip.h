@@ -46,7 +46,10 @@ enum {
   SGMCMC_SAVE_STATE = 4,   /* copy theta,g,m to prev_* first (verlet_sgld.py:72-83) */
   SGMCMC_CALC_METRICS = 8, /* update est_temperature / est_config_temp */
   SGMCMC_UNALIGNED = 16,   /* some theta/g base pointer is not 16-byte aligned: scalar loads */
-  SGMCMC_NO_MOMENTUM = 32  /* SGLD with momentum == 0: m is neither read nor written */
+  SGMCMC_NO_MOMENTUM = 32, /* SGLD with momentum == 0: m is neither read nor written */
+  SGMCMC_SMALL_FINALIZE = 64 /* few chunks: one workgroup finalizes all segments and leaves
+                                scalars[3] = sum_s(delta_energy_s + point_energy_s) for the
+                                gradient / momentum of THIS transition */
 };
 /* element-wise priors the step kernel can differentiate in-flight (prior/loc_scale.py) */
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
@@ -95,7 +98,9 @@ typedef struct {
   void* prev_m;
   double* partials;        /* device [n_chunks][SGMCMC_NSUMS] scratch */
   sgmcmc_seg_state* state; /* device [n_seg] */
-  double* scalars;         /* device [8] outputs: [0] total delta energy, [1] non-finite flag */
+  double* scalars;         /* device [8] outputs: [0] sgmcmc_delta_energy total, [1] non-finite flag,
+                              [2] fused log-prior total, [3] energy total of the last transition
+                              (SGMCMC_SMALL_FINALIZE only) */
 } sgmcmc_layout;
 
 /* Scalars of one transition of one parameter group, computed by the host in

@@ -240,3 +240,17 @@ def test_hip_reproduces_reference_goldens(name, dtype_name):
                 u_eps=2.0 ** -23)
     else:
         compare(rec, golden(dtype_name), name, rtol=1e-9, atol=1e-10)
+
+
+def test_small_finalize_energy_total_equals_delta_energy():
+    "scalars[3] of the fused launch == delta_energy(0, 0) recomputed from the current gradient"
+    for kind in ("verlet", "hmc"):
+        params, opt, fa, g = _setup(kind, torch.float32, 0.9 if kind == "verlet" else 1.0, 1.0)
+        assert opt.engine.small_finalize
+        opt.sample_momentum()
+        for k, call in enumerate(("initial_step", "step", "step", "final_step")):
+            _set_grads(params, fa, g, torch.float32)
+            getattr(opt, call)()
+            fast = opt.delta_energy_of_last_transition(0.25, 0.5)
+            slow = opt.delta_energy(0.25, 0.5)
+            assert fast == pytest.approx(slow, rel=1e-12, abs=1e-12), (kind, call)
