@@ -48,18 +48,39 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
     ap.add_argument("--sweep-log2", type=int, default=26, help="flat-arena roofline point, log2(elements); 0 = skip")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph capture (for comparison)")
     return ap.parse_args()
 
 
-def make_data(workload, n_pool, device, seed):
-    _, xshape, _, _ = WORKLOADS[workload]
-    g = torch.Generator(device=device).manual_seed(seed)
-    if workload == "googleresnet":
-        x = torch.randn((n_pool, 128) + xshape, generator=g, device=device)
-    else:
-        x = torch.rand((n_pool, 128) + xshape, generator=g, device=device)
-    y = torch.randint(0, 10, (n_pool, 128), generator=g, device=device)
-    return [(x[i], y[i]) for i in range(n_pool)]
+class PoolSource:
+    """Synthetic device-resident data set of ``n_pool`` minibatches, with the interface the
+    runner expects from its batch source (tensor batches for the exact-gradient pass, index
+    batches for the fused dense step)."""
+    fast = True
+
+    def __init__(self, workload, n_pool, device, seed):
+        _, xshape, _, _ = WORKLOADS[workload]
+        g = torch.Generator(device=device).manual_seed(seed)
+        n = n_pool * 128
+        if workload == "googleresnet":
+            self.x = torch.randn((n,) + xshape, generator=g, device=device)
+        else:
+            self.x = torch.rand((n,) + xshape, generator=g, device=device)
+        self.y = torch.randint(0, 10, (n,), generator=g, device=device)
+        self.n_pool = n_pool
+
+    def __len__(self):
+        return self.n_pool
+
+    def __iter__(self):
+        for b in range(self.n_pool):
+            yield self.x[128 * b:128 * (b + 1)], self.y[128 * b:128 * (b + 1)]
+
+    def index_batches(self):
+        import numpy as np
+        from bnn_priors_amd.fused_dense import IndexBatch
+        for b in range(self.n_pool):
+            yield IndexBatch(np.arange(128 * b, 128 * (b + 1), dtype=np.int64), self.x, self.y), None
 
 
 def make_model(workload, device):
@@ -125,7 +146,7 @@ def main():
     L = -(-N // 128)
     model = make_model(args.workload, device)
     n_params = sum(p.numel() for p in model.parameters())
-    batches = make_data(args.workload, 16, device, 1234 + rank)
+    pool = PoolSource(args.workload, 16, device, 1234 + rank)
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
     runner = VerletSGLDRunnerReject(
@@ -135,9 +156,14 @@ def main():
         metrics_saver=MemoryMetrics(), model_saver=None, reject_samples=True,
         seed=1234, chain_id=rank)
     # the exact initial gradient over the synthetic pool stands in for the full-data pass
-    runner._batch_source = batches
+    runner._batch_source = pool
+    runner.use_graph = not args.eager
     step = runner.begin()
     eng = runner.optimizer.engine
+    fused = runner._fused_dense() is not None
+    batches = list(pool.index_batches()) if fused else list(pool)
+    path = ("fused-dense 3-kernel hipGraph" if fused else
+            "eager" if args.eager else "hipGraph of autograd fwd/bwd + fused sampler")
 
     def run(k, step):
         for _ in range(k):
@@ -147,8 +173,6 @@ def main():
         return step
 
     step = run(args.warmup, step)
-    if not args.no_kernel_timing:
-        eng.start_kernel_timing()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -163,8 +187,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    ktimes = [] if args.no_kernel_timing else eng.stop_kernel_timing()
     runner._check_finite()
+    # Live duration of the fused sampler kernel: HIP events cannot bracket a node inside a graph
+    # replay, so the same launches (same arena, same arguments) are issued eagerly right here,
+    # each bracketed by an event pair on its stream.  rocprofv3's per-dispatch durations of the
+    # in-graph launches are in profiles/ and agree.
+    ktimes = []
+    if not args.no_kernel_timing:
+        opt = runner.optimizer
+        if any(p.grad is None for p in eng.params):
+            x, y = next(iter(pool))
+            runner._model_potential_and_grad(x, y, False)
+        eng.start_kernel_timing()
+        for _ in range(200):
+            opt.step(calc_metrics=False)
+        ktimes = eng.stop_kernel_timing()
     out = {
         "metric": "leapfrog steps/sec, VerletSGLDReject", "value": round(world * args.steps / dt, 2),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -173,7 +210,8 @@ def main():
         "config": {"workload": f"{name} VerletSGLDReject batch=128 N={N} (L={L} steps/epoch) "
                                f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip=10 prior={prior}",
                    "params": n_params, "tensors": len(list(model.parameters())),
-                   "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"},
+                   "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
+                   "step_path": path},
     }
     if rank == 0:
         if ktimes:
@@ -194,7 +232,7 @@ def main():
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
-            cpu_batches = [(x.cpu(), y.cpu()) for x, y in batches]
+            cpu_batches = [(x.cpu(), y.cpu()) for x, y in pool]
             res = time_cpu_baseline(lambda: make_model(args.workload, "cpu"), cpu_batches,
                                     num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
                                     steps_per_cycle=L * 50, budget_s=args.cpu_budget)

@@ -15,14 +15,18 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
-SOURCE = os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")
+SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip"), os.path.join(_HERE, "csrc", "mlp_hip.hip")]
+SOURCE = SOURCES[0]
 
 ABI_VERSION = 1
 CHUNK = 4096
 NSUMS = 6
+PSTRIDE = 8
+MLP_ROWS = 16
 F32, F64 = 0, 1
 VERLET, HMC, SGLD = 0, 1, 2
 INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM, SMALL_FINALIZE = 1, 2, 4, 8, 16, 32, 64
+WITH_LOG_PRIOR = 128
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T = 0, 1, 2, 3
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
@@ -61,6 +65,20 @@ class StepArgs(ctypes.Structure):
                 ("stream", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
+class MlpArgs(ctypes.Structure):
+    _fields_ = [("X", ctypes.c_void_p), ("Y", ctypes.c_void_p), ("idx", ctypes.c_void_p),
+                ("W1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("W2", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("W3", ctypes.c_void_p), ("b3", ctypes.c_void_p),
+                ("gpart", ctypes.c_void_p), ("loss_part", ctypes.c_void_p),
+                ("correct_part", ctypes.c_void_p), ("gpart_stride", ctypes.c_int64),
+                ("off_W1", ctypes.c_int64), ("off_b1", ctypes.c_int64), ("off_W2", ctypes.c_int64),
+                ("off_b2", ctypes.c_int64), ("off_W3", ctypes.c_int64), ("off_b3", ctypes.c_int64),
+                ("batch", ctypes.c_int32), ("in_features", ctypes.c_int32),
+                ("hidden1", ctypes.c_int32), ("hidden2", ctypes.c_int32),
+                ("out_features", ctypes.c_int32), ("inv_softmax_temp", ctypes.c_float),
+                ("trace", ctypes.c_void_p)]
+
+
 EXPORTS = {
     "sgmcmc_abi_version": (ctypes.c_int, []),
     "sgmcmc_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -85,6 +103,12 @@ EXPORTS = {
                                           ctypes.c_void_p]),
     "sgmcmc_prior_grad": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_double, ctypes.c_int,
                                          ctypes.c_uint32, ctypes.c_void_p]),
+    "sgmcmc_mlp_fwdbwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.c_void_p]),
+    "sgmcmc_mlp_lds_bytes": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_grad_reduce_prior": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                                ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),
@@ -127,7 +151,7 @@ def build(verbose=False):
     """hipcc cross-compile for gfx950 (works without a GPU)."""
     import subprocess
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, SOURCE, "-o", LIB_PATH]
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -333,7 +333,7 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       }
     }
   }
-  block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_NSUMS);
+  block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_PSTRIDE);
 }
 
 template <typename T, int KIND, bool VEC>
@@ -379,6 +379,8 @@ __device__ __forceinline__ void segment_reduce(const double* __restrict__ partia
 __device__ __forceinline__ int64_t seg_chunks(const sgmcmc_segment& s) {
   return (s.numel + SGMCMC_CHUNK - 1) / SGMCMC_CHUNK;
 }
+
+__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s);  // defined with the prior kernels
 
 // Scalar bookkeeping of one segment after its six sums S are known (thread-serial).
 // Returns the segment's contribution to delta_energy's loop: state.delta_energy + point energy
@@ -430,7 +432,7 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
   const int seg = A.seg_begin + blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[SGMCMC_NSUMS];
-  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
   segment_bookkeeping(L, A, seg, s, S);
 }
@@ -442,7 +444,8 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
 // further reduction launches.
 __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
   __shared__ double terms[kThreads];
-  double total = 0.0;
+  __shared__ double lps[kThreads];
+  double total = 0.0, lp_total = 0.0;
   for (int base = A.seg_begin; base < A.seg_end; base += kThreads) {
     const int seg = base + (int)threadIdx.x;
     double term = 0.0;
@@ -452,19 +455,33 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
       const int64_t n = seg_chunks(s);
       for (int64_t c = 0; c < n; ++c) {
 #pragma unroll
-        for (int k = 0; k < SGMCMC_NSUMS; ++k) S[k] += L.partials[(s.first_chunk + c) * SGMCMC_NSUMS + k];
+        for (int k = 0; k < SGMCMC_NSUMS; ++k) S[k] += L.partials[(s.first_chunk + c) * SGMCMC_PSTRIDE + k];
       }
       term = segment_bookkeeping(L, A, seg, s, S);
+      if ((A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS)) {
+        double lp = 0.0;
+        for (int64_t c = 0; c < n; ++c) lp += L.partials[(s.first_chunk + c) * SGMCMC_PSTRIDE + 6];
+        lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : lp + (double)s.numel * prior_log_norm(s);
+        L.state[seg].aux = lp;
+        lps[threadIdx.x] = lp;
+      } else {
+        lps[threadIdx.x] = 0.0;
+      }
+    } else {
+      lps[threadIdx.x] = 0.0;
     }
     terms[threadIdx.x] = term;
     __syncthreads();
     if (threadIdx.x == 0) {
       const int m = A.seg_end - base < kThreads ? A.seg_end - base : kThreads;
-      for (int i = 0; i < m; ++i) total += terms[i];
+      for (int i = 0; i < m; ++i) { total += terms[i]; lp_total += lps[i]; }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) L.scalars[3] = total;
+  if (threadIdx.x == 0) {
+    L.scalars[3] = total;
+    if ((A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS)) L.scalars[2] = lp_total;
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(kThreads) void dot_kernel(sgmcmc_layout L, int whic
       }
     }
   }
-  block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_NSUMS);
+  block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_PSTRIDE);
 }
 
 // mode 0: state.aux = segment sum ; mode 1 (Verlet) / 2 (HMC): state.point_energy
@@ -564,7 +581,7 @@ __global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L,
   const int seg = blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[1];
-  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
   sgmcmc_seg_state* st = &L.state[seg];
   if (mode == 0) st->aux = S[0];
@@ -576,17 +593,38 @@ __global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L,
 // d/dtheta of -log p(theta)/N and (optionally) log p(theta), element-wise families with scalar
 // loc/scale/df (SURVEY.md Appendix A "Priors").  The gradient is applied in the working precision
 // with one rounding for the factor and one fma into g; log p is evaluated and accumulated in fp64.
+__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s) {
+  // per-element normalising constant of the density
+  if (s.prior_kind == SGMCMC_PRIOR_NORMAL) return -log(s.prior_scale) - 0.9189385332046727418;
+  if (s.prior_kind == SGMCMC_PRIOR_LAPLACE) return -log(2.0 * s.prior_scale);
+  if (s.prior_kind == SGMCMC_PRIOR_STUDENT_T)
+    return -log(s.prior_scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
+           lgamma(0.5 * s.prior_df) + lgamma(0.5 * (s.prior_df + 1.0));
+  return 0.0;
+}
+
+struct GradParts {          // optional: likelihood gradient given as per-slice partials
+  const float* gpart;       // [n_slices][stride], element (seg, j) at noise_base_seg + j
+  int n_slices;
+  int64_t stride;
+  const float* loss_part;   // [n_slices]
+  const float* correct_part;
+  int batch;
+};
+
 template <typename T>
-__global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double num_data,
-                                                         int calc_logp) {
+__device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_data, bool calc_logp,
+                                           const GradParts& G) {
   const int64_t chunk = blockIdx.x;
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
   const int kind = sp->prior_kind;
+  const bool parts = G.gpart != nullptr;
   double acc[1] = {0.0};
-  if (kind != SGMCMC_PRIOR_NONE) {
+  if (kind != SGMCMC_PRIOR_NONE || parts) {
     T* __restrict__ gp = (T*)sp->g + cx.seg_off;
     const T* __restrict__ thp = (const T*)sp->theta + cx.seg_off;
+    const float* __restrict__ pp = parts ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
     const double loc = sp->prior_loc, scale = sp->prior_scale, df = sp->prior_df;
     const T locT = (T)loc;
     const T c_normal = (T)(1.0 / (scale * scale * num_data));
@@ -596,11 +634,31 @@ __global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double
       const int j = (it * kThreads + threadIdx.x) * 4;
       const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
       if (n <= 0) break;
-      Item<T> g = load_guarded<T>(gp + j, n);
+      Item<T> g;
+      if (parts) {  // fixed-order sum over the slices (deterministic)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) g.x[l] = T(0);
+        if (n == 4) {  // partial rows are 16-byte aligned (packed offsets are multiples of 4)
+#pragma unroll 8
+          for (int sl = 0; sl < G.n_slices; ++sl) {
+            const float4 q = *reinterpret_cast<const float4*>(pp + (int64_t)sl * G.stride + j);
+            g.x[0] += (T)q.x; g.x[1] += (T)q.y; g.x[2] += (T)q.z; g.x[3] += (T)q.w;
+          }
+        } else {
+          for (int sl = 0; sl < G.n_slices; ++sl) {
+            const float* q = pp + (int64_t)sl * G.stride + j;
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+              if (l < n) g.x[l] += (T)q[l];
+          }
+        }
+      } else {
+        g = load_guarded<T>(gp + j, n);
+      }
       const Item<T> th = load_guarded<T>(thp + j, n);
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
-        if (l < n) {
+        if (l < n && kind != SGMCMC_PRIOR_NONE) {
           const T d = th.x[l] - locT;
           if (kind == SGMCMC_PRIOR_NORMAL) {
             g.x[l] = fma_t<T>(d, c_normal, g.x[l]);
@@ -621,23 +679,34 @@ __global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double
       store_guarded<T>(gp + j, g, n);
     }
   }
-  if (calc_logp) block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_NSUMS);
+  if (calc_logp) block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_PSTRIDE + 6);
+  if (parts && blockIdx.x == 0 && threadIdx.x == 0) {
+    double l = 0.0, c = 0.0;
+    for (int sl = 0; sl < G.n_slices; ++sl) { l += (double)G.loss_part[sl]; c += (double)G.correct_part[sl]; }
+    L.scalars[4] = l / (double)G.batch;
+    L.scalars[5] = c / (double)G.batch;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double num_data,
+                                                         int calc_logp, GradParts G) {
+  prior_body<T>(L, num_data, calc_logp != 0, G);
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void prior_kernel_indirect(sgmcmc_layout L, double num_data,
+                                                                  const sgmcmc_step_args* Ap,
+                                                                  GradParts G) {
+  prior_body<T>(L, num_data, (Ap->flags & SGMCMC_CALC_METRICS) != 0, G);
 }
 
 __global__ __launch_bounds__(kThreads) void finalize_prior_kernel(sgmcmc_layout L) {
   const int seg = blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[1];
-  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_NSUMS, S);
+  segment_reduce<1>(L.partials + 6, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
-  double norm = 0.0;  // per-element normalising constant of the density
-  const double n = (double)s.numel;
-  if (s.prior_kind == SGMCMC_PRIOR_NORMAL) norm = -log(s.prior_scale) - 0.9189385332046727418;
-  else if (s.prior_kind == SGMCMC_PRIOR_LAPLACE) norm = -log(2.0 * s.prior_scale);
-  else if (s.prior_kind == SGMCMC_PRIOR_STUDENT_T)
-    norm = -log(s.prior_scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
-           lgamma(0.5 * s.prior_df) + lgamma(0.5 * (s.prior_df + 1.0));
-  L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + n * norm;
+  L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + (double)s.numel * prior_log_norm(s);
 }
 
 __global__ void total_prior_kernel(sgmcmc_layout L) {
@@ -826,14 +895,33 @@ int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob
   if (!L || L->n_chunks <= 0 || !(num_data > 0)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1};
   if (L->dtype == SGMCMC_F32)
-    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob);
+    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
   else
-    hipLaunchKernelGGL(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob);
+    hipLaunchKernelGGL(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
   if (calc_log_prob) {
     hipLaunchKernelGGL(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
     hipLaunchKernelGGL(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
   }
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_slices,
+                             int64_t stride, const float* loss_part, const float* correct_part,
+                             int batch, double num_data, uint32_t flags,
+                             const sgmcmc_step_args* A_dev, void* stream) {
+  if (!L || L->n_chunks <= 0 || !(num_data > 0) || !gpart || n_slices <= 0 || batch <= 0 ||
+      L->dtype != SGMCMC_F32)
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)L->n_chunks), block(kThreads);
+  const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch};
+  if (A_dev)
+    hipLaunchKernelGGL(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
+  else
+    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data,
+                       (int)((flags & SGMCMC_CALC_METRICS) != 0), G);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,200 @@
+"""Whole leapfrog step of the dense classifier as a 3-kernel hipGraph.
+
+For ``ClassificationDenseNet`` (Linear-ReLU-Linear-ReLU-Linear, categorical likelihood,
+element-wise priors; reference models/dense_nets.py:48-67) a leapfrog step is
+
+    [one async copy: per-step scalars + the minibatch's row indices]
+    mlp_fwdbwd_kernel       fused forward + backward on the matrix cores, rows gathered by
+                            index from the device-resident data set      (csrc/mlp_hip.hip)
+    prior_kernel_indirect   fixed-order sum of the per-slice partial gradients + prior
+                            gradient (+ log-prior partials on metric steps)
+    step_kernel_indirect    fused sampler transition (noise, momentum, position, RMSprop, dots)
+    finalize_small_kernel   energy / temperature bookkeeping, energy total, log-prior total
+
+captured once per batch size and replayed; metric steps read ONE buffer back.  Numerically
+the gradient differs from the autograd path only by fp32 summation order (tested against a
+PyTorch reference in tests/test_fused_dense.py); everything downstream is the same code.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _hip
+from .models.base import ClassificationModel
+
+
+class IndexBatch:
+    """A minibatch named by its row indices into a device-resident data set."""
+    __slots__ = ("idx", "X", "Y")
+
+    def __init__(self, idx, X, Y):
+        self.idx, self.X, self.Y = idx, X, Y      # idx: int64 numpy array (host)
+
+    def __len__(self):
+        return len(self.idx)
+
+    def materialize(self):
+        i = torch.from_numpy(np.ascontiguousarray(self.idx)).to(self.X.device)
+        return self.X.index_select(0, i), self.Y.index_select(0, i)
+
+
+def _dense_layers(model):
+    "the three Linear layers if ``model`` is the supported topology, else None"
+    if not isinstance(model, ClassificationModel) or not isinstance(model.softmax_temp, (int, float)):
+        return None
+    net = getattr(model.net, "module", model.net)
+    if not isinstance(net, nn.Sequential) or len(net) != 5:
+        return None
+    lin = [net[0], net[2], net[4]]
+    if not all(isinstance(net[i], nn.ReLU) for i in (1, 3)):
+        return None
+    from .models.layers import Linear
+    for l in lin:
+        if not isinstance(l, Linear) or l.bias_prior is None:
+            return None
+    return lin
+
+
+class FusedDenseLeapfrog:
+    @staticmethod
+    def supported(potential, optimizer):
+        lin = _dense_layers(potential.model)
+        eng = optimizer.engine
+        if lin is None or not potential.fast or potential.leftover or not eng.small_finalize:
+            return False
+        if eng.dtype != torch.float32 or len(optimizer.param_groups) != 1:
+            return False
+        want = [t for l in lin for t in (l.weight_prior.p, l.bias_prior.p)]
+        if len(want) != len(eng.params) or any(a is not b for a, b in zip(want, eng.params)):
+            return False
+        (h1, i), (h2, h1b), (o, h2b) = (l.weight_prior.p.shape for l in lin)
+        return (i % 4 == 0 and h1 == h1b and h2 == h2b and h1 <= 64 and h2 <= 64 and o <= 16
+                and _hip.lib().sgmcmc_mlp_lds_bytes(i) <= 160 * 1024)
+
+    def __init__(self, potential, optimizer, X, Y, ring=8):
+        assert self.supported(potential, optimizer)
+        self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
+        self.lib = _hip.lib()
+        eng, dev = self.eng, optimizer.engine.device
+        self.X = X.to(dev, torch.float32).contiguous().view(X.shape[0], -1)
+        self.Y = Y.to(dev, torch.int64).contiguous()
+        self.lin = _dense_layers(potential.model)
+        # static gradient buffer, packed like the noise index (4-aligned per tensor)
+        self.offs = [int(o) for o in eng.seg_host["noise_base"]]
+        self.stride = self.offs[-1] + -(-eng.params[-1].numel() // 4) * 4
+        self.g_flat = torch.zeros(self.stride, device=dev)
+        self.static_grads = [self.g_flat[o:o + p.numel()].view(p.shape)
+                             for o, p in zip(self.offs, eng.params)]
+        self.nbytes_args = ctypes.sizeof(_hip.StepArgs)
+        self._ring, self._k = ring, 0
+        self._by_batch = {}
+        self._host_report = torch.empty(eng.report.shape, dtype=torch.float64).pin_memory()
+
+    # ------------------------------------------------------------------ per batch size
+    def _setup(self, batch):
+        eng, dev = self.eng, self.eng.device
+        S = -(-batch // _hip.MLP_ROWS)
+        st = dict(batch=batch, S=S)
+        st["dev"] = torch.zeros(self.nbytes_args + 8 * batch, dtype=torch.uint8, device=dev)
+        st["slots"] = [torch.zeros(self.nbytes_args + 8 * batch, dtype=torch.uint8).pin_memory()
+                       for _ in range(self._ring)]
+        st["slot_idx"] = [s.numpy()[self.nbytes_args:].view(np.int64) for s in st["slots"]]
+        st["events"] = [None] * self._ring
+        st["gpart"] = torch.zeros(S * self.stride, device=dev)
+        st["loss_part"] = torch.zeros(S, device=dev)
+        st["corr_part"] = torch.zeros(S, device=dev)
+        W1, b1, W2, b2, W3, b3 = eng.params
+        o = self.offs
+        st["mlp"] = _hip.MlpArgs(
+            X=self.X.data_ptr(), Y=self.Y.data_ptr(), idx=st["dev"].data_ptr() + self.nbytes_args,
+            W1=W1.data_ptr(), b1=b1.data_ptr(), W2=W2.data_ptr(), b2=b2.data_ptr(),
+            W3=W3.data_ptr(), b3=b3.data_ptr(), gpart=st["gpart"].data_ptr(),
+            loss_part=st["loss_part"].data_ptr(), correct_part=st["corr_part"].data_ptr(),
+            gpart_stride=self.stride, off_W1=o[0], off_b1=o[1], off_W2=o[2], off_b2=o[3],
+            off_W3=o[4], off_b3=o[5], batch=batch, in_features=W1.shape[1], hidden1=W1.shape[0],
+            hidden2=W2.shape[0], out_features=W3.shape[0],
+            inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp))
+        st["param_ptrs"] = [p.data_ptr() for p in eng.params]
+        self._bind_grads()
+        eng.refresh(self.opt._preconditioners())
+        A_host = self._args(False, advance=False)
+        # one eager pass first (code-object load, LDS attribute); it only writes scratch buffers,
+        # the static gradient and scalars[4:6], so the chain's state is untouched
+        stream = eng.stream()
+        _hip.check(self.lib.sgmcmc_mlp_fwdbwd(ctypes.byref(st["mlp"]), stream), "sgmcmc_mlp_fwdbwd")
+        _hip.check(self.lib.sgmcmc_grad_reduce_prior(
+            ctypes.byref(eng.layout), st["gpart"].data_ptr(), S, self.stride,
+            st["loss_part"].data_ptr(), st["corr_part"].data_ptr(), batch, self.pot.N, 0,
+            st["dev"].data_ptr(), stream), "sgmcmc_grad_reduce_prior")
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._enqueue(st, A_host)
+        st["graph"], st["A_host"] = graph, A_host
+        torch.cuda.synchronize(dev)
+        return st
+
+    def _enqueue(self, st, A_host):
+        eng = self.eng
+        stream = eng.stream()
+        _hip.check(self.lib.sgmcmc_mlp_fwdbwd(ctypes.byref(st["mlp"]), stream), "sgmcmc_mlp_fwdbwd")
+        _hip.check(self.lib.sgmcmc_grad_reduce_prior(
+            ctypes.byref(eng.layout), st["gpart"].data_ptr(), st["S"], self.stride,
+            st["loss_part"].data_ptr(), st["corr_part"].data_ptr(), st["batch"], self.pot.N, 0,
+            st["dev"].data_ptr(), stream), "sgmcmc_grad_reduce_prior")
+        eng.step_indirect(A_host, st["dev"].data_ptr())
+
+    def _args(self, calc_metrics, advance=True):
+        kind, flags, sc = self.opt._plain_step_spec(calc_metrics)
+        draw = self.eng.next_draw() if advance else self.eng.draw
+        return self.eng.make_args(0, kind, flags | _hip.WITH_LOG_PRIOR, draw,
+                                  grad_clamp=self.opt.grad_clamp, **sc)
+
+    def _bind_grads(self):
+        params = self.eng.params
+        if params[0].grad is not self.static_grads[0]:
+            for p, g in zip(params, self.static_grads):
+                p.grad = g
+
+    # ------------------------------------------------------------------ replay
+    def replay(self, idx, metrics=False):
+        """One leapfrog step on the rows ``idx`` (host int64 array).  Returns None, or on a
+        metric step dict(loss, acc, log_prior, energy, nonfinite) after one read-back."""
+        batch = len(idx)
+        st = self._by_batch.get(batch)
+        if st is None:
+            st = self._by_batch[batch] = self._setup(batch)
+        eng = self.eng
+        if st["param_ptrs"] != [p.data_ptr() for p in eng.params]:
+            # parameter storage moved (e.g. load_state_dict keeps it, p.data = ... does not)
+            st = self._by_batch[batch] = self._setup(batch)
+        self._bind_grads()
+        eng.refresh(self.opt._preconditioners())
+        A = self._args(metrics)
+        i = self._k % self._ring
+        self._k += 1
+        ev = st["events"][i]
+        if ev is not None:
+            ev.synchronize()
+        slot = st["slots"][i]
+        ctypes.memmove(slot.data_ptr(), ctypes.addressof(A), self.nbytes_args)
+        st["slot_idx"][i][:] = idx
+        st["dev"].copy_(slot, non_blocking=True)
+        ev = st["events"][i] = ev or torch.cuda.Event()
+        ev.record()
+        st["graph"].replay()
+        eng._touch()
+        eng.energy_ready = True
+        if not metrics:
+            return None
+        eng.metrics_ready = True
+        self._host_report.copy_(eng.report, non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        v = self._host_report.numpy()
+        eng._state_host = v[8:].reshape(eng.n_seg, -1).copy()
+        if v[1] != 0.0:
+            eng.scalars[1].zero_()
+        return dict(loss=float(v[4]), acc=float(v[5]), nonfinite=bool(v[1] != 0.0),
+                    log_prior=float(v[2]), energy=float(v[3]))

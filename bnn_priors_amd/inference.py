@@ -63,6 +63,14 @@ class _BatchSource:
         return torch.randperm(n, generator=gen)
 
     def __iter__(self):
+        return self._iterate(False)
+
+    def index_batches(self):
+        """same minibatches, same RNG consumption, but named by row index (fused_dense.IndexBatch)
+        so that a kernel can gather them itself; falls back to tensors when not ``fast``"""
+        return self._iterate(True)
+
+    def _iterate(self, by_index):
         if not self.fast:
             for x, y in self.dl:
                 yield x.to(self.device), y.to(self.device)
@@ -73,9 +81,15 @@ class _BatchSource:
         # RNG stream aligned with a run that iterates the DataLoader itself
         torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
         perm = self._permutation()
+        stop = n - n % bs if self.dl.drop_last else n
+        if by_index:
+            from .fused_dense import IndexBatch
+            host = (perm if perm is not None else torch.arange(n)).numpy()
+            for i in range(0, stop, bs):
+                yield IndexBatch(host[i:i + bs], self.x, self.y), None
+            return
         if perm is not None:
             perm = perm.to(self.device)
-        stop = n - n % bs if self.dl.drop_last else n
         for i in range(0, stop, bs):
             if perm is None:
                 yield self.x[i:i + bs], self.y[i:i + bs]

@@ -30,6 +30,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
         self.cycle_seed = cycle_seed
         self.use_graph = use_graph
         self._graphed = None
+        self._fused = None
 
     def _make_optimizer(self, params):
         return mcmc.VerletSGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
@@ -46,9 +47,13 @@ class VerletSGLDRunnerReject(SGLDRunner):
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
         store = (step % self.metrics_skip) == 0
         opt, N = self.optimizer, self.eff_num_data
-        graphed = self._graph_for(x, y)
+        by_index = y is None          # an IndexBatch from _BatchSource.index_batches()
+        if by_index and self._fused_dense() is None:
+            x, y = x.materialize()
+            by_index = False
+        graphed = self._fused_dense() if by_index else self._graph_for(x, y)
         if graphed is not None:
-            r = graphed.replay(x, y, metrics=store)
+            r = graphed.replay(x.idx, metrics=store) if by_index else graphed.replay(x, y, metrics=store)
             acc = None
             if store:
                 if r["nonfinite"]:
@@ -63,8 +68,8 @@ class VerletSGLDRunnerReject(SGLDRunner):
                 acc = r["acc"]
             if not last_of_epoch:
                 self.scheduler.step()
-            elif acc is None:
-                acc = self._potential().accuracy(x, y)       # quirk 5: the sample row logs it
+            elif acc is None:                                # quirk 5: the sample row logs it
+                acc = self._potential().accuracy(*(x.materialize() if by_index else (x, y)))
             return acc
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
         opt.step(calc_metrics=store)
@@ -88,6 +93,30 @@ class VerletSGLDRunnerReject(SGLDRunner):
         has already reduced it; samplers without that shortcut use ``delta_energy``"""
         fn = getattr(self.optimizer, "delta_energy_of_last_transition", self.optimizer.delta_energy)
         return fn(self._initial_potential, potential)
+
+    def _fused_dense(self):
+        """the 3-kernel fused step (fused_dense.py) when the model is the dense classifier and the
+        data set is device resident; None otherwise"""
+        if not self.use_graph or self._fused is False:
+            return None
+        if self._fused is None:
+            from .fused_dense import FusedDenseLeapfrog
+            src = self._batches()
+            pot = self._potential()
+            if (getattr(src, "fast", False) and pot.fast
+                    and FusedDenseLeapfrog.supported(pot, self.optimizer)):
+                self._fused = FusedDenseLeapfrog(pot, self.optimizer, src.x, src.y)
+            else:
+                self._fused = False
+                return None
+        return self._fused
+
+    def _hot_batches(self):
+        "minibatches of one epoch for the leapfrog loop: by index when the fused step can gather them"
+        src = self._batches()
+        if self._fused_dense() is not None and hasattr(src, "index_batches"):
+            return src.index_batches()
+        return iter(src)
 
     def _graph_for(self, x, y):
         """the captured graph if this step can use it (fused potential, matching batch shape)"""
@@ -146,7 +175,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                     # same minibatch order in every epoch of the cycle (:84)
                     generator.set_state(cycle_random_state)
                     n_batches = len(batches)
-                    for i, (x, y) in enumerate(batches):
+                    for i, (x, y) in enumerate(self._hot_batches()):
                         step += 1
                         acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
 

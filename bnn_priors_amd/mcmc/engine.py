@@ -97,10 +97,12 @@ class Engine:
         self.m = torch.zeros(total, dtype=dt, device=dev)
         self.v = torch.ones(total, dtype=dt, device=dev)
         self.prev_theta = self.prev_g = self.prev_m = None
-        self.partials = torch.zeros(self.n_chunks * _hip.NSUMS, dtype=torch.float64, device=dev)
-        self.state_dev = torch.zeros(self.n_seg * len(_hip.SEG_STATE_FIELDS), dtype=torch.float64,
-                                     device=dev)
-        self.scalars = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.partials = torch.zeros(self.n_chunks * _hip.PSTRIDE, dtype=torch.float64, device=dev)
+        # scalars[8] and the per-segment state array share ONE buffer so a metric step reads
+        # everything back with a single copy
+        self.report = torch.zeros(8 + self.n_seg * len(_hip.SEG_STATE_FIELDS), dtype=torch.float64,
+                                  device=dev)
+        self.scalars, self.state_dev = self.report[:8], self.report[8:]
         self.layout = _hip.Layout()
         self._fill_layout()
         self._state_host = None      # cached D2H copy of state_dev

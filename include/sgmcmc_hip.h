@@ -36,6 +36,8 @@ extern "C" {
 #define SGMCMC_ABI_VERSION 1
 #define SGMCMC_CHUNK 4096 /* elements per arena chunk = 256 threads x 4 items x 4 elements */
 #define SGMCMC_NSUMS 6
+#define SGMCMC_PSTRIDE 8   /* doubles per chunk in `partials`: the 6 sums, [6] log-prior, [7] spare */
+#define SGMCMC_MLP_ROWS 16 /* batch rows per workgroup of the fused dense-net kernel */
 
 enum { SGMCMC_F32 = 0, SGMCMC_F64 = 1 };
 enum { SGMCMC_VERLET = 0, SGMCMC_HMC = 1, SGMCMC_SGLD = 2 };
@@ -47,9 +49,12 @@ enum {
   SGMCMC_CALC_METRICS = 8, /* update est_temperature / est_config_temp */
   SGMCMC_UNALIGNED = 16,   /* some theta/g base pointer is not 16-byte aligned: scalar loads */
   SGMCMC_NO_MOMENTUM = 32, /* SGLD with momentum == 0: m is neither read nor written */
-  SGMCMC_SMALL_FINALIZE = 64 /* few chunks: one workgroup finalizes all segments and leaves
-                                scalars[3] = sum_s(delta_energy_s + point_energy_s) for the
-                                gradient / momentum of THIS transition */
+  SGMCMC_SMALL_FINALIZE = 64, /* few chunks: one workgroup finalizes all segments and leaves
+                                 scalars[3] = sum_s(delta_energy_s + point_energy_s) for the
+                                 gradient / momentum of THIS transition */
+  SGMCMC_WITH_LOG_PRIOR = 128 /* with SMALL_FINALIZE + CALC_METRICS: partials[.][6] holds the
+                                 fused priors' log-density partials (sgmcmc_grad_reduce_prior):
+                                 finish state[s].aux and scalars[2] in the same launch */
 };
 /* element-wise priors the step kernel can differentiate in-flight (prior/loc_scale.py) */
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
@@ -96,11 +101,12 @@ typedef struct {
   void* prev_theta;
   void* prev_g;
   void* prev_m;
-  double* partials;        /* device [n_chunks][SGMCMC_NSUMS] scratch */
+  double* partials;        /* device [n_chunks][SGMCMC_PSTRIDE] scratch */
   sgmcmc_seg_state* state; /* device [n_seg] */
   double* scalars;         /* device [8] outputs: [0] sgmcmc_delta_energy total, [1] non-finite flag,
                               [2] fused log-prior total, [3] energy total of the last transition
-                              (SGMCMC_SMALL_FINALIZE only) */
+                              (SGMCMC_SMALL_FINALIZE only), [4] minibatch loss, [5] minibatch
+                              accuracy (sgmcmc_grad_reduce_prior) */
 } sgmcmc_layout;
 
 /* Scalars of one transition of one parameter group, computed by the host in
@@ -182,6 +188,42 @@ int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* 
  * One launch for all tensors instead of ~10 ATen launches per prior tensor per step. */
 int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob, uint32_t flags,
                       void* stream);
+
+/* ---- fused dense classifier (ClassificationDenseNet, models/dense_nets.py:48-67) ---------- */
+/* Forward + backward of -(1/B) sum_i log softmax(net(x_i) / T)[y_i] for
+ * net = Linear(in,h1)-ReLU-Linear(h1,h2)-ReLU-Linear(h2,out), fp32, in ONE launch
+ * (csrc/mlp_hip.hip).  Rows are gathered as X[idx[b]], Y[idx[b]] (idx == NULL: b itself).
+ * Workgroup s writes its 16 rows' PARTIAL gradients to gpart + s*gpart_stride at the given
+ * per-tensor offsets, and loss_part[s] = sum of its rows' losses, correct_part[s] = #correct.
+ * Limits: in % 4 == 0, h1,h2 <= 64, out <= 16, LDS(in) <= 160 KiB. */
+typedef struct {
+  const float* X;      /* [n_data, in]  device */
+  const int64_t* Y;    /* [n_data]      device */
+  const int64_t* idx;  /* [batch] device, or NULL */
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+  float* gpart;        /* [ceil(batch/16)][gpart_stride] */
+  float* loss_part;    /* [ceil(batch/16)] */
+  float* correct_part; /* [ceil(batch/16)] */
+  int64_t gpart_stride;
+  int64_t off_W1, off_b1, off_W2, off_b2, off_W3, off_b3;
+  int32_t batch, in_features, hidden1, hidden2, out_features;
+  float inv_softmax_temp;
+  int64_t* trace; /* optional (else NULL): 9 clock64() stamps at the phase boundaries of workgroup 0 */
+} sgmcmc_mlp_args;
+
+int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream);
+int64_t sgmcmc_mlp_lds_bytes(int in_features);
+
+/* g <- sum_{s<n_slices} gpart[s*stride + noise_base_seg + j]  (fixed order)  - (1/N) dlog p/dtheta,
+ * written to each segment's g; i.e. sgmcmc_prior_grad with the likelihood gradient taken from
+ * per-slice partials (fp32 layouts only).  Also scalars[4] <- sum(loss_part)/batch,
+ * scalars[5] <- sum(correct_part)/batch.  The log-density partials are produced when
+ * (A_dev ? A_dev->flags : flags) has SGMCMC_CALC_METRICS and are finished by the following
+ * sgmcmc_step* launch carrying SGMCMC_WITH_LOG_PRIOR. */
+int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_slices,
+                             int64_t stride, const float* loss_part, const float* correct_part,
+                             int batch, double num_data, uint32_t flags,
+                             const sgmcmc_step_args* A_dev, void* stream);
 
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,

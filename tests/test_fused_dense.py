@@ -1,0 +1,85 @@
+"""Fused dense-classifier kernel (csrc/mlp_hip.hip) against a plain PyTorch fp32
+reference of the same op: gradients of mean cross-entropy of a 3-layer ReLU MLP."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run_kernel(X, Y, idx, Ws, batch, temp=1.0):
+    from bnn_priors_amd import _hip
+    W1, b1, W2, b2, W3, b3 = Ws
+    sizes = [t.numel() for t in Ws]
+    offs, acc = [], 0
+    for n in sizes:
+        offs.append(acc)
+        acc += -(-n // 4) * 4
+    slices = -(-batch // _hip.MLP_ROWS)
+    gpart = torch.full((slices, acc), float("nan"), device=DEV)
+    loss_part = torch.zeros(slices, device=DEV)
+    corr_part = torch.zeros(slices, device=DEV)
+    A = _hip.MlpArgs(X=X.data_ptr(), Y=Y.data_ptr(), idx=idx.data_ptr() if idx is not None else None,
+                     W1=W1.data_ptr(), b1=b1.data_ptr(), W2=W2.data_ptr(), b2=b2.data_ptr(),
+                     W3=W3.data_ptr(), b3=b3.data_ptr(), gpart=gpart.data_ptr(),
+                     loss_part=loss_part.data_ptr(), correct_part=corr_part.data_ptr(),
+                     gpart_stride=acc, off_W1=offs[0], off_b1=offs[1], off_W2=offs[2], off_b2=offs[3],
+                     off_W3=offs[4], off_b3=offs[5], batch=batch, in_features=W1.shape[1],
+                     hidden1=W1.shape[0], hidden2=W2.shape[0], out_features=W3.shape[0],
+                     inv_softmax_temp=1.0 / temp)
+    _hip.check(_hip.lib().sgmcmc_mlp_fwdbwd(ctypes.byref(A),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "mlp_fwdbwd")
+    torch.cuda.synchronize()
+    grads = [gpart[:, o:o + n].sum(0).view(t.shape) for o, n, t in zip(offs, sizes, Ws)]
+    return grads, loss_part.sum().item() / batch, corr_part.sum().item() / batch, gpart
+
+
+@pytest.mark.parametrize("dims,batch,n_data,temp", [
+    ((784, 50, 50, 10), 128, 1000, 1.0),      # the BASELINE classificationdensenet
+    ((784, 50, 50, 10), 96, 1000, 1.0),       # last minibatch of an MNIST epoch (60000 % 128)
+    ((20, 8, 8, 10), 32, 32, 1.0),            # the tiny golden net
+    ((36, 64, 33, 16), 100, 300, 2.5),        # ragged slice, full-width tiles, softmax temperature
+    ((4, 1, 1, 2), 5, 9, 1.0),
+])
+def test_mlp_fwdbwd_matches_torch(dims, batch, n_data, temp):
+    IN, H1, H2, OUT = dims
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(n_data, IN, generator=g).to(DEV)
+    Y = torch.randint(0, OUT, (n_data,), generator=g).to(DEV)
+    idx = torch.randperm(n_data, generator=g)[:batch].to(DEV)
+    mk = lambda *s: (torch.randn(*s, generator=g) * (1.5 / max(s[-1], 1) ** 0.5)).to(DEV).requires_grad_(True)  # noqa: E731
+    Ws = [mk(H1, IN), mk(H1), mk(H2, H1), mk(H2), mk(OUT, H2), mk(OUT)]
+    grads, loss, acc, gpart = _run_kernel(X, Y, idx, [w.detach() for w in Ws], batch, temp)
+
+    x, y = X[idx], Y[idx]
+    h1 = F.relu(F.linear(x, Ws[0], Ws[1]))
+    h2 = F.relu(F.linear(h1, Ws[2], Ws[3]))
+    f = F.linear(h2, Ws[4], Ws[5]) / temp
+    ref_loss = F.cross_entropy(f, y)
+    ref_loss.backward()
+    assert loss == pytest.approx(ref_loss.item(), rel=2e-6, abs=1e-6)
+    assert acc == pytest.approx((f.argmax(1) == y).float().mean().item(), abs=1e-7)
+    for got, w in zip(grads, Ws):
+        scale = w.grad.abs().max().item() + 1e-12
+        # same fp32 products, different summation order than rocBLAS: a few ulp of the largest term
+        assert (got - w.grad).abs().max().item() <= 2e-6 * scale + 1e-9, (got - w.grad).abs().max().item() / scale
+    # no partial outside the tensors' extents was touched except the 4-alignment pads (left NaN)
+    assert torch.isnan(gpart).sum().item() == gpart.shape[0] * sum((-t.numel()) % 4 for t in Ws)
+
+
+def test_mlp_fwdbwd_identity_index_and_determinism():
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(128, 784, generator=g).to(DEV)
+    Y = torch.randint(0, 10, (128,), generator=g).to(DEV)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.05).to(DEV)  # noqa: E731
+    Ws = [mk(50, 784), mk(50), mk(50, 50), mk(50), mk(10, 50), mk(10)]
+    a = _run_kernel(X, Y, None, Ws, 128)
+    b = _run_kernel(X, Y, torch.arange(128, device=DEV), Ws, 128)
+    for u, v in zip(a[0], b[0]):
+        assert torch.equal(u, v)
+    assert a[1] == b[1]
