@@ -18,8 +18,9 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip"), os.path.join(_HERE, "csrc", "mlp_hip.hip")]
 SOURCE = SOURCES[0]
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CHUNK = 4096
+CHUNK_SMALL = 1024
 NSUMS = 6
 PSTRIDE = 8
 MLP_ROWS = 16
@@ -46,7 +47,7 @@ assert SEGMENT_DTYPE.itemsize == 80 and CHUNK_DTYPE.itemsize == 8
 
 class Layout(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int32), ("n_seg", ctypes.c_int32), ("n_chunks", ctypes.c_int64),
-                ("segs", ctypes.c_void_p), ("chunks", ctypes.c_void_p),
+                ("chunk_elems", ctypes.c_int64), ("segs", ctypes.c_void_p), ("chunks", ctypes.c_void_p),
                 ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("prev_theta", ctypes.c_void_p),
                 ("prev_g", ctypes.c_void_p), ("prev_m", ctypes.c_void_p),
                 ("partials", ctypes.c_void_p), ("state", ctypes.c_void_p),
@@ -63,6 +64,13 @@ class StepArgs(ctypes.Structure):
                 ("rmsprop_alpha", ctypes.c_double), ("grad_clamp", ctypes.c_double),
                 ("seed", ctypes.c_uint64), ("draw", ctypes.c_uint64),
                 ("stream", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class GradParts(ctypes.Structure):
+    _fields_ = [("gpart", ctypes.c_void_p), ("loss_part", ctypes.c_void_p),
+                ("correct_part", ctypes.c_void_p), ("stride", ctypes.c_int64),
+                ("num_data", ctypes.c_double), ("n_slices", ctypes.c_int32),
+                ("batch", ctypes.c_int32)]
 
 
 class MlpArgs(ctypes.Structure):
@@ -87,6 +95,9 @@ EXPORTS = {
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_step_indirect": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
                                             ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_step_indirect_parts": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
+                                                  ctypes.c_void_p, ctypes.POINTER(GradParts),
+                                                  ctypes.c_void_p]),
     "sgmcmc_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sgmcmc_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "sgmcmc_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
@@ -109,6 +120,13 @@ EXPORTS = {
                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_dense_stepper_create": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(MlpArgs),
+                                                   ctypes.POINTER(StepArgs), ctypes.c_double,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "sgmcmc_dense_stepper_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StepArgs),
+                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_dense_stepper_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -20,6 +20,7 @@
 // run-to-run bitwise reproducible), which also adds the prior's gradient.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "sgmcmc_hip.h"
 
@@ -372,6 +373,96 @@ int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream) {
   hipLaunchKernelGGL(mlp_fwdbwd_kernel, dim3((unsigned)slices), dim3(kThreads), (size_t)lds,
                      (hipStream_t)stream, *P);
   return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- native stepper
+struct sgmcmc_dense_stepper {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t capture_stream = nullptr;
+  hipEvent_t* events = nullptr;
+  unsigned char* used = nullptr;
+  unsigned char* pinned = nullptr;
+  void* dev_args = nullptr;
+  int n_ring = 0, batch = 0;
+  int64_t slot_bytes = 0;
+  uint64_t k = 0;
+};
+
+int sgmcmc_dense_stepper_create(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
+                                const sgmcmc_step_args* A_geometry, double num_data,
+                                void* dev_args, void* pinned, int n_ring, int64_t slot_bytes,
+                                sgmcmc_dense_stepper** out) {
+  if (!L || !mlp || !A_geometry || !dev_args || !pinned || n_ring <= 0 || !out ||
+      slot_bytes < (int64_t)sizeof(sgmcmc_step_args) + 8 * (int64_t)mlp->batch)
+    return (int)hipErrorInvalidValue;
+  sgmcmc_dense_stepper* S = new sgmcmc_dense_stepper();
+  S->n_ring = n_ring; S->batch = mlp->batch; S->slot_bytes = slot_bytes;
+  S->pinned = (unsigned char*)pinned; S->dev_args = dev_args;
+  S->events = new hipEvent_t[n_ring];
+  S->used = new unsigned char[n_ring]();
+  hipError_t err = hipStreamCreateWithFlags(&S->capture_stream, hipStreamNonBlocking);
+  for (int i = 0; i < n_ring && err == hipSuccess; ++i)
+    err = hipEventCreateWithFlags(&S->events[i], hipEventDisableTiming);
+  if (err != hipSuccess) return (int)err;
+  // one eager pass first: loads the code objects and sets the LDS attribute outside capture
+  int rc = sgmcmc_mlp_fwdbwd(mlp, S->capture_stream);
+  if (rc) return rc;
+  err = hipStreamSynchronize(S->capture_stream);
+  if (err != hipSuccess) return (int)err;
+  err = hipStreamBeginCapture(S->capture_stream, hipStreamCaptureModeThreadLocal);
+  if (err != hipSuccess) return (int)err;
+  const int slices = (mlp->batch + SGMCMC_MLP_ROWS - 1) / SGMCMC_MLP_ROWS;
+  rc = sgmcmc_mlp_fwdbwd(mlp, S->capture_stream);
+  if (!rc) {
+    sgmcmc_grad_parts G;
+    G.gpart = mlp->gpart; G.loss_part = mlp->loss_part; G.correct_part = mlp->correct_part;
+    G.stride = mlp->gpart_stride; G.num_data = num_data; G.n_slices = slices; G.batch = mlp->batch;
+    rc = sgmcmc_step_indirect_parts(L, A_geometry, (const sgmcmc_step_args*)dev_args, &G,
+                                    S->capture_stream);
+  }
+  err = hipStreamEndCapture(S->capture_stream, &S->graph);
+  if (rc) return rc;
+  if (err != hipSuccess) return (int)err;
+  err = hipGraphInstantiate(&S->exec, S->graph, nullptr, nullptr, 0);
+  if (err != hipSuccess) return (int)err;
+  *out = S;
+  return 0;
+}
+
+int sgmcmc_dense_stepper_step(sgmcmc_dense_stepper* S, const sgmcmc_step_args* A,
+                              const int64_t* idx_host, void* stream) {
+  if (!S || !A || !idx_host) return (int)hipErrorInvalidValue;
+  const int i = (int)(S->k % (uint64_t)S->n_ring);
+  ++S->k;
+  hipError_t err;
+  if (S->used[i]) {
+    err = hipEventSynchronize(S->events[i]);
+    if (err != hipSuccess) return (int)err;
+  }
+  unsigned char* slot = S->pinned + (int64_t)i * S->slot_bytes;
+  memcpy(slot, A, sizeof(sgmcmc_step_args));
+  memcpy(slot + sizeof(sgmcmc_step_args), idx_host, 8 * (size_t)S->batch);
+  hipStream_t s = (hipStream_t)stream;
+  err = hipMemcpyAsync(S->dev_args, slot, sizeof(sgmcmc_step_args) + 8 * (size_t)S->batch,
+                       hipMemcpyHostToDevice, s);
+  if (err != hipSuccess) return (int)err;
+  err = hipEventRecord(S->events[i], s);
+  if (err != hipSuccess) return (int)err;
+  S->used[i] = 1;
+  return (int)hipGraphLaunch(S->exec, s);
+}
+
+int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S) {
+  if (!S) return 0;
+  if (S->exec) (void)hipGraphExecDestroy(S->exec);
+  if (S->graph) (void)hipGraphDestroy(S->graph);
+  for (int i = 0; i < S->n_ring; ++i) (void)hipEventDestroy(S->events[i]);
+  if (S->capture_stream) (void)hipStreamDestroy(S->capture_stream);
+  delete[] S->events;
+  delete[] S->used;
+  delete S;
+  return 0;
 }
 
 }  // extern "C"

@@ -27,8 +27,9 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kItems = SGMCMC_CHUNK / (kThreads * 4);  // 4
-static_assert(kItems * kThreads * 4 == SGMCMC_CHUNK, "chunk geometry");
+constexpr int kItemElems = kThreads * 4;  // elements covered by one item of every thread (1024)
+static_assert(SGMCMC_CHUNK % kItemElems == 0 && SGMCMC_CHUNK_SMALL == kItemElems, "chunk geometry");
+__device__ __forceinline__ int items_of(const sgmcmc_layout& L) { return (int)(L.chunk_elems / kItemElems); }
 
 // ------------------------------------------------------------------ noise
 // Philox4x32-10; counter layout and transforms: DESIGN.md "Noise".
@@ -189,8 +190,8 @@ __device__ __forceinline__ ChunkCtx chunk_ctx(const sgmcmc_layout& L, int64_t ch
   ChunkCtx c;
   c.seg = ce.seg;
   c.n_valid = ce.n_valid;
-  c.seg_off = (chunk - L.segs[ce.seg].first_chunk) * (int64_t)SGMCMC_CHUNK;
-  c.arena_off = chunk * (int64_t)SGMCMC_CHUNK;
+  c.seg_off = (chunk - L.segs[ce.seg].first_chunk) * L.chunk_elems;
+  c.arena_off = chunk * L.chunk_elems;
   return c;
 }
 
@@ -229,8 +230,89 @@ __device__ __forceinline__ void update_elem(const Coef<T, KIND>& C, T xi, T gi, 
   v_new = vv * C.alpha + (C.one_m_alpha * gi) * gi;     // :195-197
 }
 
-template <typename T, int KIND, bool VEC>
-__device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
+// Optional in-flight assembly of the gradient (fused dense path): likelihood part as per-slice
+// partials, prior part in closed form.  `gpart == nullptr`: g is taken from the segment as is.
+struct GradParts {
+  const float* gpart;       // [n_slices][stride], element (seg, j) at noise_base_seg + j
+  int n_slices;
+  int64_t stride;
+  const float* loss_part;   // [n_slices]
+  const float* correct_part;
+  int batch;
+  double num_data;
+};
+
+__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s);  // defined with the prior kernels
+
+// d/dtheta[-log p(theta)/N] added to g, and (optionally) the un-normalised log-density into lp
+template <typename T>
+struct PriorCoef {
+  int kind;
+  double loc, scale, df;
+  T locT, c_normal, c_laplace, c_t_num, c_t_den;
+  __device__ __forceinline__ void init(const sgmcmc_segment* sp, double num_data) {
+    kind = sp->prior_kind;
+    loc = sp->prior_loc; scale = sp->prior_scale; df = sp->prior_df;
+    locT = (T)loc;
+    c_normal = (T)(1.0 / (scale * scale * num_data));
+    c_laplace = (T)(1.0 / (scale * num_data));
+    c_t_num = (T)((df + 1.0) / num_data);
+    c_t_den = (T)(df * scale * scale);
+  }
+  __device__ __forceinline__ T apply(T g, T th, bool calc_logp, double& lp) const {
+    if (kind == SGMCMC_PRIOR_NONE) return g;
+    const T d = th - locT;
+    if (kind == SGMCMC_PRIOR_NORMAL) {
+      g = fma_t<T>(d, c_normal, g);
+    } else if (kind == SGMCMC_PRIOR_LAPLACE) {
+      const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
+      g = fma_t<T>(sgn, c_laplace, g);
+    } else {
+      g = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g);
+    }
+    if (calc_logp) {
+      const double z = ((double)th - loc) / scale;
+      if (kind == SGMCMC_PRIOR_NORMAL) lp += -0.5 * z * z;
+      else if (kind == SGMCMC_PRIOR_LAPLACE) lp += -fabs(z);
+      else lp += -0.5 * (df + 1.0) * log1p(z * z / df);
+    }
+    return g;
+  }
+};
+
+// fixed-order sum of the slices' partial gradients for the 4 elements at packed offset q
+template <typename T>
+__device__ __forceinline__ Item<T> sum_parts(const float* __restrict__ q, int n_slices, int64_t stride,
+                                             int n) {
+  Item<T> g{{T(0), T(0), T(0), T(0)}};
+  if (n == 4) {  // partial rows are 16-byte aligned (packed offsets are multiples of 4)
+#pragma unroll 8
+    for (int sl = 0; sl < n_slices; ++sl) {
+      const float4 v = *reinterpret_cast<const float4*>(q + (int64_t)sl * stride);
+      g.x[0] += (T)v.x; g.x[1] += (T)v.y; g.x[2] += (T)v.z; g.x[3] += (T)v.w;
+    }
+  } else {
+    for (int sl = 0; sl < n_slices; ++sl) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+        if (l < n) g.x[l] += (T)q[(int64_t)sl * stride + l];
+    }
+  }
+  return g;
+}
+
+__device__ __forceinline__ void publish_batch_stats(const sgmcmc_layout& L, const GradParts& G) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double l = 0.0, c = 0.0;
+    for (int sl = 0; sl < G.n_slices; ++sl) { l += (double)G.loss_part[sl]; c += (double)G.correct_part[sl]; }
+    L.scalars[4] = l / (double)G.batch;
+    L.scalars[5] = c / (double)G.batch;
+  }
+}
+
+template <typename T, int KIND, bool VEC, int ITEMS, bool PARTS>
+__device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A,
+                                          const GradParts& G) {
   const int64_t chunk = A.chunk_begin + blockIdx.x;
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
@@ -253,8 +335,9 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   // SGLD's final step modifies nothing (sgld.py:80-85); Verlet/HMC's writes m only.
   const bool write_m = !C.no_mom && !(KIND == SGMCMC_SGLD && C.is_final);
   const bool draw_noise = (KIND != SGMCMC_HMC) && C.has_noise && !(KIND == SGMCMC_SGLD && C.is_final);
+  const bool calc_logp = PARTS && (A.flags & SGMCMC_CALC_METRICS);
 
-  const T* __restrict__ gp = (const T*)sp->g + cx.seg_off;
+  T* __restrict__ gp = (T*)sp->g + cx.seg_off;
   T* __restrict__ thp = (T*)sp->theta + cx.seg_off;
   T* __restrict__ mp = (T*)L.m + cx.arena_off;
   T* __restrict__ vp = (T*)L.v + cx.arena_off;
@@ -262,16 +345,21 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   T* __restrict__ pg = (T*)L.prev_g + cx.arena_off;
   T* __restrict__ pm = (T*)L.prev_m + cx.arena_off;
   const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
+  const float* __restrict__ pp = PARTS ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
+  PriorCoef<T> PC;
+  if (PARTS) PC.init(sp, G.num_data);
 
   double acc[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
+  double lp = 0.0;
 
-  if (VEC && cx.n_valid == SGMCMC_CHUNK) {
+  if (VEC && cx.n_valid == ITEMS * kItemElems) {
     // full chunk: issue every load first, then compute
-    Item<T> g[kItems], m[kItems], th[kItems], v[kItems];
+    Item<T> g[ITEMS], m[ITEMS], th[ITEMS], v[ITEMS];
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
-      g[it] = load_item<T>(gp + j);
+      if (PARTS) g[it] = sum_parts<T>(pp + j, G.n_slices, G.stride, 4);
+      else g[it] = load_item<T>(gp + j);
       th[it] = load_item<T>(thp + j);
       if (!C.no_mom) m[it] = load_item<T>(mp + j);
       else m[it] = Item<T>{{T(0), T(0), T(0), T(0)}};
@@ -279,17 +367,19 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       else v[it] = Item<T>{{T(0), T(0), T(0), T(0)}};
     }
 #pragma unroll
-    for (int it = 0; it < kItems; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
       float z[4] = {0.f, 0.f, 0.f, 0.f};
       if (draw_noise) spec_normal4(A.seed, A.stream, A.draw, 0u, (noise0 + (uint64_t)j) >> 2, z);
       Item<T> mn, tn, vn;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
+        if (PARTS) g[it].x[l] = PC.apply(g[it].x[l], th[it].x[l], calc_logp, lp);
         if (C.do_clamp) g[it].x[l] = clamp_grad<T>(g[it].x[l], C.clampv);
         update_elem<T, KIND>(C, (T)z[l], g[it].x[l], m[it].x[l], th[it].x[l], v[it].x[l], mn.x[l],
                              tn.x[l], vn.x[l], acc);
       }
+      if (PARTS) store_item<T>(gp + j, g[it]);  // p.grad holds the full gradient afterwards
       if (save) {
         store_item<T>(pth + j, th[it]);
         store_item<T>(pg + j, g[it]);
@@ -303,11 +393,12 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
     }
   } else {
     // ragged tail chunk of a segment, or unaligned base pointers: guarded scalar accesses
-    for (int it = 0; it < kItems; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
       const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
       if (n <= 0) break;
-      Item<T> g = load_guarded<T>(gp + j, n), th = load_guarded<T>(thp + j, n);
+      Item<T> g = PARTS ? sum_parts<T>(pp + j, G.n_slices, G.stride, n) : load_guarded<T>(gp + j, n);
+      Item<T> th = load_guarded<T>(thp + j, n);
       Item<T> m = C.no_mom ? Item<T>{{T(0), T(0), T(0), T(0)}} : load_guarded<T>(mp + j, n);
       Item<T> v = C.is_final ? Item<T>{{T(0), T(0), T(0), T(0)}} : load_guarded<T>(vp + j, n);
       float z[4] = {0.f, 0.f, 0.f, 0.f};
@@ -316,11 +407,13 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
         if (l < n) {
+          if (PARTS) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, lp);
           if (C.do_clamp) g.x[l] = clamp_grad<T>(g.x[l], C.clampv);
           update_elem<T, KIND>(C, (T)z[l], g.x[l], m.x[l], th.x[l], v.x[l], mn.x[l], tn.x[l],
                                vn.x[l], acc);
         }
       }
+      if (PARTS) store_guarded<T>(gp + j, g, n);
       if (save) {
         store_guarded<T>(pth + j, th, n);
         store_guarded<T>(pg + j, g, n);
@@ -333,19 +426,34 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       }
     }
   }
-  block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_PSTRIDE);
+  if (PARTS) {
+    double a7[SGMCMC_NSUMS + 1] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], lp};
+    block_reduce_store<SGMCMC_NSUMS + 1>(a7, L.partials + chunk * SGMCMC_PSTRIDE);
+    publish_batch_stats(L, G);
+  } else {
+    block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_PSTRIDE);
+  }
 }
 
-template <typename T, int KIND, bool VEC>
+template <typename T, int KIND, bool VEC, int ITEMS>
 __global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
-  step_body<T, KIND, VEC>(L, A);
+  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
+  step_body<T, KIND, VEC, ITEMS, false>(L, A, none);
 }
 // scalars fetched from device memory at run time (graph replay)
-template <typename T, int KIND, bool VEC>
+template <typename T, int KIND, bool VEC, int ITEMS>
 __global__ __launch_bounds__(kThreads) void step_kernel_indirect(sgmcmc_layout L,
                                                                  const sgmcmc_step_args* Ap) {
   const sgmcmc_step_args A = *Ap;
-  step_body<T, KIND, VEC>(L, A);
+  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
+  step_body<T, KIND, VEC, ITEMS, false>(L, A, none);
+}
+// ... and the gradient assembled in flight from per-slice partials + closed-form prior
+template <typename T, int KIND, bool VEC, int ITEMS>
+__global__ __launch_bounds__(kThreads) void step_kernel_parts(sgmcmc_layout L,
+                                                              const sgmcmc_step_args* Ap, GradParts G) {
+  const sgmcmc_step_args A = *Ap;
+  step_body<T, KIND, VEC, ITEMS, true>(L, A, G);
 }
 
 // ------------------------------------------------------------------ per-segment finalize
@@ -376,11 +484,9 @@ __device__ __forceinline__ void segment_reduce(const double* __restrict__ partia
   for (int k = 0; k < NS; ++k) out[k] = sh[k][0];
 }
 
-__device__ __forceinline__ int64_t seg_chunks(const sgmcmc_segment& s) {
-  return (s.numel + SGMCMC_CHUNK - 1) / SGMCMC_CHUNK;
+__device__ __forceinline__ int64_t seg_chunks(const sgmcmc_layout& L, const sgmcmc_segment& s) {
+  return (s.numel + L.chunk_elems - 1) / L.chunk_elems;
 }
-
-__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s);  // defined with the prior kernels
 
 // Scalar bookkeeping of one segment after its six sums S are known (thread-serial).
 // Returns the segment's contribution to delta_energy's loop: state.delta_energy + point energy
@@ -432,7 +538,7 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
   const int seg = A.seg_begin + blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[SGMCMC_NSUMS];
-  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
+  segment_reduce<SGMCMC_NSUMS>(L.partials, s.first_chunk, seg_chunks(L, s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
   segment_bookkeeping(L, A, seg, s, S);
 }
@@ -443,44 +549,42 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
 // VerletSGLD.delta_energy for the gradient this transition used, so a metric step needs no
 // further reduction launches.
 __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
-  __shared__ double terms[kThreads];
-  __shared__ double lps[kThreads];
-  double total = 0.0, lp_total = 0.0;
-  for (int base = A.seg_begin; base < A.seg_end; base += kThreads) {
-    const int seg = base + (int)threadIdx.x;
-    double term = 0.0;
-    if (seg < A.seg_end) {
-      const sgmcmc_segment s = L.segs[seg];
-      double S[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
-      const int64_t n = seg_chunks(s);
-      for (int64_t c = 0; c < n; ++c) {
+  // wave w owns segments seg_begin + w, + 4, ...: its 64 lanes stride over the segment's chunk
+  // partials (all loads independent), then a fixed shuffle tree; lane 0 does the bookkeeping.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool with_lp = (A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS);
+  for (int seg = A.seg_begin + wave; seg < A.seg_end; seg += kThreads / 64) {
+    const sgmcmc_segment s = L.segs[seg];
+    const int64_t n = seg_chunks(L, s);
+    double S[SGMCMC_NSUMS + 1] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t c = lane; c < n; c += 64) {
+      const double* __restrict__ q = L.partials + (s.first_chunk + c) * SGMCMC_PSTRIDE;
 #pragma unroll
-        for (int k = 0; k < SGMCMC_NSUMS; ++k) S[k] += L.partials[(s.first_chunk + c) * SGMCMC_PSTRIDE + k];
-      }
-      term = segment_bookkeeping(L, A, seg, s, S);
-      if ((A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS)) {
-        double lp = 0.0;
-        for (int64_t c = 0; c < n; ++c) lp += L.partials[(s.first_chunk + c) * SGMCMC_PSTRIDE + 6];
-        lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : lp + (double)s.numel * prior_log_norm(s);
-        L.state[seg].aux = lp;
-        lps[threadIdx.x] = lp;
-      } else {
-        lps[threadIdx.x] = 0.0;
-      }
-    } else {
-      lps[threadIdx.x] = 0.0;
+      for (int k = 0; k < SGMCMC_NSUMS + 1; ++k) S[k] += q[k];
     }
-    terms[threadIdx.x] = term;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int m = A.seg_end - base < kThreads ? A.seg_end - base : kThreads;
-      for (int i = 0; i < m; ++i) { total += terms[i]; lp_total += lps[i]; }
+#pragma unroll
+    for (int k = 0; k < SGMCMC_NSUMS + 1; ++k) {
+      double x = S[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      S[k] = x;
     }
-    __syncthreads();
+    if (lane == 0) {
+      double S6[SGMCMC_NSUMS] = {S[0], S[1], S[2], S[3], S[4], S[5]};
+      segment_bookkeeping(L, A, seg, s, S6);
+      if (with_lp)
+        L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s);
+    }
   }
+  __syncthreads();  // the per-segment results written above are visible to thread 0 below
   if (threadIdx.x == 0) {
+    double total = 0.0, lp_total = 0.0;  // segment order, as the reference's Python loop
+    for (int seg = A.seg_begin; seg < A.seg_end; ++seg) {
+      total += L.state[seg].delta_energy + L.state[seg].point_energy;
+      if (with_lp) lp_total += L.state[seg].aux;
+    }
     L.scalars[3] = total;
-    if ((A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS)) L.scalars[2] = lp_total;
+    if (with_lp) L.scalars[2] = lp_total;
   }
 }
 
@@ -513,7 +617,7 @@ __global__ __launch_bounds__(kThreads) void sample_momentum_kernel(sgmcmc_layout
   T* __restrict__ mp = (T*)L.m + cx.arena_off;
   const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
   const T sd = (T)std_, sk = (T)sqrt(keep);
-  for (int it = 0; it < kItems; ++it) {
+  for (int it = 0; it < items_of(L); ++it) {
     const int j = (it * kThreads + threadIdx.x) * 4;
     const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
     if (n <= 0) break;
@@ -539,7 +643,7 @@ __global__ __launch_bounds__(kThreads) void restore_kernel(sgmcmc_layout L, int 
   const T* __restrict__ pth = (const T*)L.prev_theta + cx.arena_off;
   const T* __restrict__ pg = (const T*)L.prev_g + cx.arena_off;
   const T* __restrict__ pm = (const T*)L.prev_m + cx.arena_off;
-  for (int it = 0; it < kItems; ++it) {
+  for (int it = 0; it < items_of(L); ++it) {
     const int j = (it * kThreads + threadIdx.x) * 4;
     const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
     if (n <= 0) break;
@@ -558,7 +662,7 @@ __global__ __launch_bounds__(kThreads) void dot_kernel(sgmcmc_layout L, int whic
   const T* __restrict__ src = which == 2 ? (const T*)sp->g + cx.seg_off
                                          : (const T*)(which == 1 ? L.m : L.v) + cx.arena_off;
   double acc[1] = {0.0};
-  for (int it = 0; it < kItems; ++it) {
+  for (int it = 0; it < items_of(L); ++it) {
     const int j = (it * kThreads + threadIdx.x) * 4;
     const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
     if (n <= 0) break;
@@ -581,7 +685,7 @@ __global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L,
   const int seg = blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[1];
-  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
+  segment_reduce<1>(L.partials, s.first_chunk, seg_chunks(L, s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
   sgmcmc_seg_state* st = &L.state[seg];
   if (mode == 0) st->aux = S[0];
@@ -603,89 +707,34 @@ __device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s) {
   return 0.0;
 }
 
-struct GradParts {          // optional: likelihood gradient given as per-slice partials
-  const float* gpart;       // [n_slices][stride], element (seg, j) at noise_base_seg + j
-  int n_slices;
-  int64_t stride;
-  const float* loss_part;   // [n_slices]
-  const float* correct_part;
-  int batch;
-};
-
 template <typename T>
 __device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_data, bool calc_logp,
                                            const GradParts& G) {
   const int64_t chunk = blockIdx.x;
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
-  const int kind = sp->prior_kind;
   const bool parts = G.gpart != nullptr;
   double acc[1] = {0.0};
-  if (kind != SGMCMC_PRIOR_NONE || parts) {
+  if (sp->prior_kind != SGMCMC_PRIOR_NONE || parts) {
     T* __restrict__ gp = (T*)sp->g + cx.seg_off;
     const T* __restrict__ thp = (const T*)sp->theta + cx.seg_off;
     const float* __restrict__ pp = parts ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
-    const double loc = sp->prior_loc, scale = sp->prior_scale, df = sp->prior_df;
-    const T locT = (T)loc;
-    const T c_normal = (T)(1.0 / (scale * scale * num_data));
-    const T c_laplace = (T)(1.0 / (scale * num_data));
-    const T c_t_num = (T)((df + 1.0) / num_data), c_t_den = (T)(df * scale * scale);
-    for (int it = 0; it < kItems; ++it) {
+    PriorCoef<T> PC;
+    PC.init(sp, num_data);
+    for (int it = 0; it < items_of(L); ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
       const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
       if (n <= 0) break;
-      Item<T> g;
-      if (parts) {  // fixed-order sum over the slices (deterministic)
-#pragma unroll
-        for (int l = 0; l < 4; ++l) g.x[l] = T(0);
-        if (n == 4) {  // partial rows are 16-byte aligned (packed offsets are multiples of 4)
-#pragma unroll 8
-          for (int sl = 0; sl < G.n_slices; ++sl) {
-            const float4 q = *reinterpret_cast<const float4*>(pp + (int64_t)sl * G.stride + j);
-            g.x[0] += (T)q.x; g.x[1] += (T)q.y; g.x[2] += (T)q.z; g.x[3] += (T)q.w;
-          }
-        } else {
-          for (int sl = 0; sl < G.n_slices; ++sl) {
-            const float* q = pp + (int64_t)sl * G.stride + j;
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-              if (l < n) g.x[l] += (T)q[l];
-          }
-        }
-      } else {
-        g = load_guarded<T>(gp + j, n);
-      }
+      Item<T> g = parts ? sum_parts<T>(pp + j, G.n_slices, G.stride, n) : load_guarded<T>(gp + j, n);
       const Item<T> th = load_guarded<T>(thp + j, n);
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        if (l < n && kind != SGMCMC_PRIOR_NONE) {
-          const T d = th.x[l] - locT;
-          if (kind == SGMCMC_PRIOR_NORMAL) {
-            g.x[l] = fma_t<T>(d, c_normal, g.x[l]);
-          } else if (kind == SGMCMC_PRIOR_LAPLACE) {
-            const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
-            g.x[l] = fma_t<T>(sgn, c_laplace, g.x[l]);
-          } else {
-            g.x[l] = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g.x[l]);
-          }
-          if (calc_logp) {
-            const double z = ((double)th.x[l] - loc) / scale;
-            if (kind == SGMCMC_PRIOR_NORMAL) acc[0] += -0.5 * z * z;
-            else if (kind == SGMCMC_PRIOR_LAPLACE) acc[0] += -fabs(z);
-            else acc[0] += -0.5 * (df + 1.0) * log1p(z * z / df);
-          }
-        }
-      }
+      for (int l = 0; l < 4; ++l)
+        if (l < n) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, acc[0]);
       store_guarded<T>(gp + j, g, n);
     }
   }
   if (calc_logp) block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_PSTRIDE + 6);
-  if (parts && blockIdx.x == 0 && threadIdx.x == 0) {
-    double l = 0.0, c = 0.0;
-    for (int sl = 0; sl < G.n_slices; ++sl) { l += (double)G.loss_part[sl]; c += (double)G.correct_part[sl]; }
-    L.scalars[4] = l / (double)G.batch;
-    L.scalars[5] = c / (double)G.batch;
-  }
+  if (parts) publish_batch_stats(L, G);
 }
 
 template <typename T>
@@ -704,7 +753,7 @@ __global__ __launch_bounds__(kThreads) void finalize_prior_kernel(sgmcmc_layout 
   const int seg = blockIdx.x;
   const sgmcmc_segment s = L.segs[seg];
   double S[1];
-  segment_reduce<1>(L.partials + 6, s.first_chunk, seg_chunks(s), SGMCMC_PSTRIDE, S);
+  segment_reduce<1>(L.partials + 6, s.first_chunk, seg_chunks(L, s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
   L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + (double)s.numel * prior_log_norm(s);
 }
@@ -738,24 +787,57 @@ __global__ void debug_normals_kernel(float* out, int64_t start, int64_t n, uint6
   }
 }
 
-template <typename T, bool VEC>
-void launch_step_kind(const sgmcmc_layout& L, const sgmcmc_step_args& A, hipStream_t s) {
+// mode 0: scalars by value; 1: scalars from device memory; 2: that + gradient assembled in flight
+template <typename T, int KIND, bool VEC, int ITEMS>
+void launch_step_mode(const sgmcmc_layout& L, const sgmcmc_step_args& A, const sgmcmc_step_args* Ad,
+                      const GradParts* G, hipStream_t s) {
   const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
+  if (G) hipLaunchKernelGGL((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
+  else if (Ad) hipLaunchKernelGGL((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
+  else hipLaunchKernelGGL((step_kernel<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A);
+}
+
+template <typename T, bool VEC, int ITEMS>
+void launch_step_kind(const sgmcmc_layout& L, const sgmcmc_step_args& A, const sgmcmc_step_args* Ad,
+                      const GradParts* G, hipStream_t s) {
   switch (A.kind) {
-    case SGMCMC_VERLET: hipLaunchKernelGGL((step_kernel<T, SGMCMC_VERLET, VEC>), grid, block, 0, s, L, A); break;
-    case SGMCMC_HMC: hipLaunchKernelGGL((step_kernel<T, SGMCMC_HMC, VEC>), grid, block, 0, s, L, A); break;
-    default: hipLaunchKernelGGL((step_kernel<T, SGMCMC_SGLD, VEC>), grid, block, 0, s, L, A); break;
+    case SGMCMC_VERLET: launch_step_mode<T, SGMCMC_VERLET, VEC, ITEMS>(L, A, Ad, G, s); break;
+    case SGMCMC_HMC: launch_step_mode<T, SGMCMC_HMC, VEC, ITEMS>(L, A, Ad, G, s); break;
+    default: launch_step_mode<T, SGMCMC_SGLD, VEC, ITEMS>(L, A, Ad, G, s); break;
   }
 }
 
-template <typename T, bool VEC>
-void launch_step_kind_indirect(const sgmcmc_layout& L, const sgmcmc_step_args& A,
-                               const sgmcmc_step_args* Ad, hipStream_t s) {
-  const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
-  switch (A.kind) {
-    case SGMCMC_VERLET: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_VERLET, VEC>), grid, block, 0, s, L, Ad); break;
-    case SGMCMC_HMC: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_HMC, VEC>), grid, block, 0, s, L, Ad); break;
-    default: hipLaunchKernelGGL((step_kernel_indirect<T, SGMCMC_SGLD, VEC>), grid, block, 0, s, L, Ad); break;
+// validates and launches the fused update kernel in the requested mode
+int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
+                const GradParts* G, hipStream_t s) {
+  if (!L || !A || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
+    return (int)hipErrorInvalidValue;
+  if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
+  if (L->chunk_elems != SGMCMC_CHUNK && L->chunk_elems != SGMCMC_CHUNK_SMALL) return (int)hipErrorInvalidValue;
+  const bool vec = !(A->flags & SGMCMC_UNALIGNED);
+  const bool small = L->chunk_elems == SGMCMC_CHUNK_SMALL;
+  if (L->dtype == SGMCMC_F32) {
+    if (small) { if (vec) launch_step_kind<float, true, 1>(*L, *A, Ad, G, s); else launch_step_kind<float, false, 1>(*L, *A, Ad, G, s); }
+    else { if (vec) launch_step_kind<float, true, 4>(*L, *A, Ad, G, s); else launch_step_kind<float, false, 4>(*L, *A, Ad, G, s); }
+  } else if (L->dtype == SGMCMC_F64 && !G) {
+    if (small) { if (vec) launch_step_kind<double, true, 1>(*L, *A, Ad, G, s); else launch_step_kind<double, false, 1>(*L, *A, Ad, G, s); }
+    else { if (vec) launch_step_kind<double, true, 4>(*L, *A, Ad, G, s); else launch_step_kind<double, false, 4>(*L, *A, Ad, G, s); }
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  return 0;
+}
+
+void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
+                     hipStream_t s) {
+  const bool small = A->flags & SGMCMC_SMALL_FINALIZE;
+  const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)), block(kThreads);
+  if (Ad) {
+    if (small) hipLaunchKernelGGL(finalize_small_kernel_indirect, grid, block, 0, s, *L, Ad);
+    else hipLaunchKernelGGL(finalize_step_kernel_indirect, grid, block, 0, s, *L, Ad);
+  } else {
+    if (small) hipLaunchKernelGGL(finalize_small_kernel, grid, block, 0, s, *L, *A);
+    else hipLaunchKernelGGL(finalize_step_kernel, grid, block, 0, s, *L, *A);
   }
 }
 
@@ -769,25 +851,12 @@ const char* sgmcmc_error_string(int err) { return hipGetErrorString((hipError_t)
 
 int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
                       void* ev_start, void* ev_stop) {
-  if (!L || !A || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
-    return (int)hipErrorInvalidValue;
-  if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = !(A->flags & SGMCMC_UNALIGNED);
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
-  if (L->dtype == SGMCMC_F32) {
-    if (vec) launch_step_kind<float, true>(*L, *A, s); else launch_step_kind<float, false>(*L, *A, s);
-  } else if (L->dtype == SGMCMC_F64) {
-    if (vec) launch_step_kind<double, true>(*L, *A, s); else launch_step_kind<double, false>(*L, *A, s);
-  } else {
-    return (int)hipErrorInvalidValue;
-  }
+  const int rc = launch_step(L, A, nullptr, nullptr, s);
+  if (rc) return rc;
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, s);
-  if (A->flags & SGMCMC_SMALL_FINALIZE)
-    hipLaunchKernelGGL(finalize_small_kernel, dim3(1), dim3(kThreads), 0, s, *L, *A);
-  else
-    hipLaunchKernelGGL(finalize_step_kernel, dim3((unsigned)(A->seg_end - A->seg_begin)),
-                       dim3(kThreads), 0, s, *L, *A);
+  launch_finalize(L, A, nullptr, s);
   return (int)hipGetLastError();
 }
 
@@ -797,25 +866,24 @@ int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream)
 
 int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
                          void* stream) {
-  if (!L || !A || !Ad || A->chunk_end <= A->chunk_begin || A->seg_end <= A->seg_begin)
-    return (int)hipErrorInvalidValue;
-  if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
+  if (!Ad) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = !(A->flags & SGMCMC_UNALIGNED);
-  if (L->dtype == SGMCMC_F32) {
-    if (vec) launch_step_kind_indirect<float, true>(*L, *A, Ad, s);
-    else launch_step_kind_indirect<float, false>(*L, *A, Ad, s);
-  } else if (L->dtype == SGMCMC_F64) {
-    if (vec) launch_step_kind_indirect<double, true>(*L, *A, Ad, s);
-    else launch_step_kind_indirect<double, false>(*L, *A, Ad, s);
-  } else {
+  const int rc = launch_step(L, A, Ad, nullptr, s);
+  if (rc) return rc;
+  launch_finalize(L, A, Ad, s);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A,
+                               const sgmcmc_step_args* Ad, const sgmcmc_grad_parts* P, void* stream) {
+  if (!Ad || !P || !P->gpart || P->n_slices <= 0 || P->batch <= 0 || !(P->num_data > 0))
     return (int)hipErrorInvalidValue;
-  }
-  if (A->flags & SGMCMC_SMALL_FINALIZE)
-    hipLaunchKernelGGL(finalize_small_kernel_indirect, dim3(1), dim3(kThreads), 0, s, *L, Ad);
-  else
-    hipLaunchKernelGGL(finalize_step_kernel_indirect, dim3((unsigned)(A->seg_end - A->seg_begin)),
-                       dim3(kThreads), 0, s, *L, Ad);
+  hipStream_t s = (hipStream_t)stream;
+  const GradParts G = {P->gpart, P->n_slices, P->stride, P->loss_part, P->correct_part, P->batch,
+                       P->num_data};
+  const int rc = launch_step(L, A, Ad, &G, s);
+  if (rc) return rc;
+  launch_finalize(L, A, Ad, s);
   return (int)hipGetLastError();
 }
 
@@ -895,7 +963,7 @@ int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob
   if (!L || L->n_chunks <= 0 || !(num_data > 0)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
-  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1};
+  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
   if (L->dtype == SGMCMC_F32)
     hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
   else
@@ -916,7 +984,7 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
-  const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch};
+  const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch, num_data};
   if (A_dev)
     hipLaunchKernelGGL(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
   else

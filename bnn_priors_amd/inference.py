@@ -25,6 +25,30 @@ from .utils import get_cosine_schedule
 __all__ = ("SGLDRunner", "VerletSGLDRunner", "HMCRunner")
 
 
+class LambdaSchedule:
+    """``torch.optim.lr_scheduler.LambdaLR`` for one multiplicative schedule, without its
+    per-call bookkeeping (~10 us of Python per step): ``group['lr'] = base_lr * fn(k)`` with
+    k = 0 at construction and +1 per ``step()`` -- the same expression and therefore the same
+    doubles as LambdaLR (torch/optim/lr_scheduler.py, LambdaLR.get_lr)."""
+
+    def __init__(self, optimizer, lr_lambda):
+        self.optimizer, self.fn = optimizer, lr_lambda
+        for g in optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
+        self.base_lrs = [g['initial_lr'] for g in optimizer.param_groups]
+        self.last_epoch = -1
+        self.step()
+
+    def step(self):
+        self.last_epoch += 1
+        f = self.fn(self.last_epoch)
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g['lr'] = base * f
+
+    def get_last_lr(self):
+        return [g['lr'] for g in self.optimizer.param_groups]
+
+
 def _is_hmc(optimizer):
     "momentum is fully refreshed before every initial step for HMC only (inference.py:312-315)"
     return isinstance(optimizer, mcmc.HMC) or getattr(optimizer, "is_hmc", False)
@@ -149,7 +173,7 @@ class SGLDRunner:
         # inference.py:96-108
         if self.sampling_decay is True or self.sampling_decay == "cosine":
             schedule = get_cosine_schedule(len(self.dataloader) * self.epochs_per_cycle)
-            return torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
+            return LambdaSchedule(optimizer, schedule)
         elif self.sampling_decay is False or self.sampling_decay == "stairs":
             return torch.optim.lr_scheduler.StepLR(optimizer, 150 * len(self.dataloader), gamma=0.1)
         elif self.sampling_decay == "flat":

@@ -53,7 +53,8 @@ class VerletSGLDRunnerReject(SGLDRunner):
             by_index = False
         graphed = self._fused_dense() if by_index else self._graph_for(x, y)
         if graphed is not None:
-            r = graphed.replay(x.idx, metrics=store) if by_index else graphed.replay(x, y, metrics=store)
+            r = (graphed.replay(x.idx, metrics=store, idx_ptr=x.ptr) if by_index
+                 else graphed.replay(x, y, metrics=store))
             acc = None
             if store:
                 if r["nonfinite"]:

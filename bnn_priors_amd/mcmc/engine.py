@@ -63,8 +63,10 @@ class Engine:
             seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
         self.seed, self.chain_id, self.draw = int(seed) & (2 ** 64 - 1), int(chain_id), 0
 
-        # ---- tables
-        C = _hip.CHUNK
+        # ---- tables.  Chunk size is a property of the layout: small models get 1024-element
+        # chunks (one 16-byte item per thread) so that they still spread over many CUs.
+        total_numel = sum(p.numel() for p in params)
+        C = self.chunk = _hip.CHUNK_SMALL if total_numel <= (1 << 20) else _hip.CHUNK
         seg = np.zeros(self.n_seg, dtype=_hip.SEGMENT_DTYPE)
         chunk_rows, first, noise = [], 0, 0
         self.group_ranges = []
@@ -89,11 +91,12 @@ class Engine:
         chunks = np.array(chunk_rows, dtype=_hip.CHUNK_DTYPE)
         self._chunk_dev = torch.from_numpy(chunks.view(np.uint8).copy()).to(dev)
         self._seg_dirty = True
+        self._precond_dirty = True    # set by SegState when a caller assigns a preconditioner
         self._ptr_cache = None
         self._unaligned = False
 
         # ---- arenas and scratch
-        total = self.n_chunks * C
+        total = self.n_chunks * self.chunk
         self.m = torch.zeros(total, dtype=dt, device=dev)
         self.v = torch.ones(total, dtype=dt, device=dev)
         self.prev_theta = self.prev_g = self.prev_m = None
@@ -111,12 +114,12 @@ class Engine:
         self.energy_ready = False
         self.hidden_keys = frozenset()   # state keys this sampler family does not have
         # few chunks: one workgroup finalizes all segments and also emits the energy total
-        self.small_finalize = len(param_groups) == 1 and self.n_chunks <= 2048
+        self.small_finalize = len(param_groups) == 1 and self.n_chunks <= 4096
 
     # ------------------------------------------------------------------ views
     def _view(self, arena, i):
         p = self.params[i]
-        off = int(self.seg_host[i]["first_chunk"]) * _hip.CHUNK
+        off = int(self.seg_host[i]["first_chunk"]) * self.chunk
         return arena[off:off + p.numel()].view(p.shape)
 
     def momentum_view(self, i):
@@ -135,7 +138,7 @@ class Engine:
     def _fill_layout(self):
         L = self.layout
         L.dtype = _hip.F32 if self.dtype == torch.float32 else _hip.F64
-        L.n_seg, L.n_chunks = self.n_seg, self.n_chunks
+        L.n_seg, L.n_chunks, L.chunk_elems = self.n_seg, self.n_chunks, self.chunk
         L.segs, L.chunks = self._seg_dev.data_ptr(), self._chunk_dev.data_ptr()
         L.m, L.v = self.m.data_ptr(), self.v.data_ptr()
         for name in ("prev_theta", "prev_g", "prev_m"):
@@ -181,6 +184,7 @@ class Engine:
             if M[i] != m:
                 M[i] = m
                 self._seg_dirty = True
+        self._precond_dirty = False
         if self._seg_dirty and not defer_upload:   # deferred: during hipGraph capture
             self._upload_segments()
 
@@ -368,6 +372,16 @@ class SegState(dict):
 
     def __contains__(self, key):
         return dict.__contains__(self, key) or self._lazy_available(key)
+
+    def __setitem__(self, key, value):
+        if key == 'preconditioner':
+            self._engine._precond_dirty = True
+        dict.__setitem__(self, key, value)
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
 
     def get(self, key, default=None):
         try:

@@ -16,11 +16,12 @@
  * Data model
  * ----------
  * A sampler instance owns an ARENA tiled into CHUNKs of SGMCMC_CHUNK elements.
- * Parameter tensor ("segment") s occupies ceil(numel_s / SGMCMC_CHUNK)
- * consecutive chunks starting at first_chunk_s; the optimizer-owned state
+ * Parameter tensor ("segment") s occupies ceil(numel_s / chunk_elems)
+ * consecutive chunks starting at first_chunk_s (chunk_elems is a property of the layout:
+ * 4096, or 1024 for small models so that they still fill many CUs); the optimizer-owned state
  * arrays m (momentum), v (RMSprop square_avg), prev_theta / prev_g / prev_m
  * (Metropolis-Hastings roll-back copies) live in the arena at element offset
- * chunk * SGMCMC_CHUNK.  theta (the nn.Parameter storage) and g (its .grad)
+ * chunk * chunk_elems.  theta (the nn.Parameter storage) and g (its .grad)
  * are NOT moved: kernels reach them through the per-segment base pointers, so
  * autograd can keep allocating gradients wherever it likes.
  */
@@ -33,8 +34,9 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 1
-#define SGMCMC_CHUNK 4096 /* elements per arena chunk = 256 threads x 4 items x 4 elements */
+#define SGMCMC_ABI_VERSION 2
+#define SGMCMC_CHUNK 4096 /* default elements per arena chunk = 256 threads x 4 items x 4 elements */
+#define SGMCMC_CHUNK_SMALL 1024 /* small models: one item per thread, 4x more workgroups */
 #define SGMCMC_NSUMS 6
 #define SGMCMC_PSTRIDE 8   /* doubles per chunk in `partials`: the 6 sums, [6] log-prior, [7] spare */
 #define SGMCMC_MLP_ROWS 16 /* batch rows per workgroup of the fused dense-net kernel */
@@ -94,6 +96,7 @@ typedef struct {
   int32_t dtype; /* SGMCMC_F32 | SGMCMC_F64 */
   int32_t n_seg;
   int64_t n_chunks;
+  int64_t chunk_elems; /* SGMCMC_CHUNK or SGMCMC_CHUNK_SMALL: elements per chunk of THIS layout */
   const sgmcmc_segment* segs; /* device [n_seg] */
   const sgmcmc_chunk* chunks; /* device [n_chunks] */
   void* m;                    /* device arenas, n_chunks * SGMCMC_CHUNK elements each */
@@ -155,6 +158,25 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
  * with a different learning rate / draw counter / flags every step. */
 int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A_host,
                          const sgmcmc_step_args* A_dev, void* stream);
+
+/* Likelihood gradient given as per-slice partials (written by sgmcmc_mlp_fwdbwd): element j of
+ * segment s lives at gpart[slice*stride + noise_base_s + j]. */
+typedef struct {
+  const float* gpart;
+  const float* loss_part;    /* [n_slices] */
+  const float* correct_part; /* [n_slices] */
+  int64_t stride;
+  double num_data;
+  int32_t n_slices, batch;
+} sgmcmc_grad_parts;
+
+/* sgmcmc_step_indirect with the gradient assembled in flight: g <- sum over slices (fixed
+ * order) - (1/N) dlog p/dtheta, used by the transition AND written back to each segment's g;
+ * on metric steps also the log-prior partials; scalars[4], [5] <- minibatch loss / accuracy.
+ * fp32 layouts only.  One launch instead of sgmcmc_grad_reduce_prior + sgmcmc_step_indirect. */
+int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A_host,
+                               const sgmcmc_step_args* A_dev, const sgmcmc_grad_parts* G,
+                               void* stream);
 int sgmcmc_event_create(void** ev);
 int sgmcmc_event_destroy(void* ev);
 int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
@@ -224,6 +246,24 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
                              int64_t stride, const float* loss_part, const float* correct_part,
                              int batch, double num_data, uint32_t flags,
                              const sgmcmc_step_args* A_dev, void* stream);
+
+/* ---- native replay of the fused dense leapfrog step ------------------------------------- */
+/* A "stepper" owns a hipGraph of  mlp_fwdbwd -> step_indirect_parts (update + finalize)  captured on
+ * an internal stream at creation, and a ring of pinned host slots.  One call to
+ * sgmcmc_dense_stepper_step per leapfrog step: copies *A (per-step scalars) and idx[batch] (row
+ * indices) into the next slot, enqueues ONE async H2D copy of the slot to `dev_args` and the
+ * graph launch on `stream`.  A slot is reused only after the copy that last read it has
+ * executed (event wait), so the host may run ahead of the GPU by up to n_ring steps.
+ * Memory is the caller's: dev_args (device, slot_bytes), pinned (host-pinned, n_ring*slot_bytes),
+ * slot_bytes >= sizeof(sgmcmc_step_args) + 8*batch; mlp->idx must be dev_args + sizeof(step_args). */
+typedef struct sgmcmc_dense_stepper sgmcmc_dense_stepper;
+int sgmcmc_dense_stepper_create(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
+                                const sgmcmc_step_args* A_geometry, double num_data,
+                                void* dev_args, void* pinned, int n_ring, int64_t slot_bytes,
+                                sgmcmc_dense_stepper** out);
+int sgmcmc_dense_stepper_step(sgmcmc_dense_stepper* S, const sgmcmc_step_args* A,
+                              const int64_t* idx_host, void* stream);
+int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S);
 
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
