@@ -84,7 +84,8 @@ class MlpArgs(ctypes.Structure):
                 ("batch", ctypes.c_int32), ("in_features", ctypes.c_int32),
                 ("hidden1", ctypes.c_int32), ("hidden2", ctypes.c_int32),
                 ("out_features", ctypes.c_int32), ("inv_softmax_temp", ctypes.c_float),
-                ("trace", ctypes.c_void_p)]
+                ("trace", ctypes.c_void_p), ("args_src", ctypes.c_void_p),
+                ("args_dst", ctypes.c_void_p), ("args_bytes", ctypes.c_int32)]
 
 
 EXPORTS = {
@@ -127,6 +128,9 @@ EXPORTS = {
     "sgmcmc_dense_stepper_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StepArgs),
                                                  ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_dense_stepper_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "sgmcmc_dense_step_direct": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(MlpArgs),
+                                                ctypes.POINTER(StepArgs), ctypes.c_double,
+                                                ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -42,7 +42,10 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(kThreads) void mlp_fwdbwd_kernel(sgmcmc_mlp_args P) {
+struct IdxBlock { int32_t idx[SGMCMC_MLP_MAX_INLINE]; };
+
+template <bool INLINE>
+__device__ __forceinline__ void mlp_fwdbwd_body(const sgmcmc_mlp_args& P, const IdxBlock* IB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int IN = P.in_features, H1 = P.hidden1, H2 = P.hidden2, OUT = P.out_features;
   const int INp = (IN + 15) & ~15;  // K of the first layer, padded to 16
@@ -74,10 +77,12 @@ __global__ __launch_bounds__(kThreads) void mlp_fwdbwd_kernel(sgmcmc_mlp_args P)
   MLP_TRACE();
 
   // ---- phase 0a: resolve the 16 row indices / labels; stage the small weights and biases
+  if (P.args_src && blockIdx.x == 0 && tid < (P.args_bytes >> 2))
+    reinterpret_cast<uint32_t*>(P.args_dst)[tid] = reinterpret_cast<const uint32_t*>(P.args_src)[tid];
   if (tid < ROWS) {
     const int b = row0 + tid;
     int64_t src = -1;
-    if (b < P.batch) src = P.idx ? P.idx[b] : (int64_t)b;
+    if (b < P.batch) src = INLINE ? (int64_t)IB->idx[b] : (P.idx ? P.idx[b] : (int64_t)b);
     rowp[tid] = src;
     ys[tid] = src >= 0 ? (int)P.Y[src] : -1;
   }
@@ -344,6 +349,13 @@ __global__ __launch_bounds__(kThreads) void mlp_fwdbwd_kernel(sgmcmc_mlp_args P)
 #undef MLP_TRACE
 }
 
+__global__ __launch_bounds__(kThreads) void mlp_fwdbwd_kernel(sgmcmc_mlp_args P) {
+  mlp_fwdbwd_body<false>(P, nullptr);
+}
+__global__ __launch_bounds__(kThreads) void mlp_fwdbwd_kernel_inline(sgmcmc_mlp_args P, IdxBlock IB) {
+  mlp_fwdbwd_body<true>(P, &IB);
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,15 +387,42 @@ int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream) {
   return (int)hipGetLastError();
 }
 
+int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
+                            const sgmcmc_grad_parts* P, void* stream);  // sgmcmc_hip.hip
+
+int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
+                             const sgmcmc_step_args* A, double num_data, const int64_t* idx_host,
+                             void* stream) {
+  if (!L || !mlp || !A || !idx_host || mlp->batch <= 0 || mlp->batch > SGMCMC_MLP_MAX_INLINE)
+    return (int)hipErrorInvalidValue;
+  if ((mlp->in_features & 3) || mlp->hidden1 > HP || mlp->hidden2 > HP || mlp->out_features > OP)
+    return (int)hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwdbwd_kernel_inline),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  IdxBlock IB;
+  for (int b = 0; b < mlp->batch; ++b) IB.idx[b] = (int32_t)idx_host[b];
+  const int slices = (mlp->batch + ROWS - 1) / ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mlp_fwdbwd_kernel_inline, dim3((unsigned)slices), dim3(kThreads),
+                     (size_t)sgmcmc_mlp_lds_bytes(mlp->in_features), s, *mlp, IB);
+  sgmcmc_grad_parts G;
+  G.gpart = mlp->gpart; G.loss_part = mlp->loss_part; G.correct_part = mlp->correct_part;
+  G.stride = mlp->gpart_stride; G.num_data = num_data; G.n_slices = slices; G.batch = mlp->batch;
+  return sgmcmc_step_parts_value(L, A, &G, s);
+}
+
 // ---------------------------------------------------------------- native stepper
 struct sgmcmc_dense_stepper {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  hipGraph_t* graphs = nullptr;       // one replica per pinned slot (its host address is baked in)
+  hipGraphExec_t* execs = nullptr;
   hipStream_t capture_stream = nullptr;
   hipEvent_t* events = nullptr;
   unsigned char* used = nullptr;
   unsigned char* pinned = nullptr;
-  void* dev_args = nullptr;
   int n_ring = 0, batch = 0;
   int64_t slot_bytes = 0;
   uint64_t k = 0;
@@ -394,38 +433,50 @@ int sgmcmc_dense_stepper_create(const sgmcmc_layout* L, const sgmcmc_mlp_args* m
                                 void* dev_args, void* pinned, int n_ring, int64_t slot_bytes,
                                 sgmcmc_dense_stepper** out) {
   if (!L || !mlp || !A_geometry || !dev_args || !pinned || n_ring <= 0 || !out ||
-      slot_bytes < (int64_t)sizeof(sgmcmc_step_args) + 8 * (int64_t)mlp->batch)
+      slot_bytes < (int64_t)sizeof(sgmcmc_step_args) + 8 * (int64_t)mlp->batch || (slot_bytes & 7))
     return (int)hipErrorInvalidValue;
   sgmcmc_dense_stepper* S = new sgmcmc_dense_stepper();
   S->n_ring = n_ring; S->batch = mlp->batch; S->slot_bytes = slot_bytes;
-  S->pinned = (unsigned char*)pinned; S->dev_args = dev_args;
+  S->pinned = (unsigned char*)pinned;
   S->events = new hipEvent_t[n_ring];
+  S->graphs = new hipGraph_t[n_ring]();
+  S->execs = new hipGraphExec_t[n_ring]();
   S->used = new unsigned char[n_ring]();
   hipError_t err = hipStreamCreateWithFlags(&S->capture_stream, hipStreamNonBlocking);
   for (int i = 0; i < n_ring && err == hipSuccess; ++i)
     err = hipEventCreateWithFlags(&S->events[i], hipEventDisableTiming);
   if (err != hipSuccess) return (int)err;
+  const int slices = (mlp->batch + SGMCMC_MLP_ROWS - 1) / SGMCMC_MLP_ROWS;
+  sgmcmc_grad_parts G;
+  G.gpart = mlp->gpart; G.loss_part = mlp->loss_part; G.correct_part = mlp->correct_part;
+  G.stride = mlp->gpart_stride; G.num_data = num_data; G.n_slices = slices; G.batch = mlp->batch;
   // one eager pass first: loads the code objects and sets the LDS attribute outside capture
-  int rc = sgmcmc_mlp_fwdbwd(mlp, S->capture_stream);
+  // (writes scratch only: idx = identity, no argument forwarding)
+  sgmcmc_mlp_args warm = *mlp;
+  warm.idx = nullptr; warm.args_src = nullptr; warm.args_dst = nullptr; warm.args_bytes = 0;
+  int rc = sgmcmc_mlp_fwdbwd(&warm, S->capture_stream);
   if (rc) return rc;
   err = hipStreamSynchronize(S->capture_stream);
   if (err != hipSuccess) return (int)err;
-  err = hipStreamBeginCapture(S->capture_stream, hipStreamCaptureModeThreadLocal);
-  if (err != hipSuccess) return (int)err;
-  const int slices = (mlp->batch + SGMCMC_MLP_ROWS - 1) / SGMCMC_MLP_ROWS;
-  rc = sgmcmc_mlp_fwdbwd(mlp, S->capture_stream);
-  if (!rc) {
-    sgmcmc_grad_parts G;
-    G.gpart = mlp->gpart; G.loss_part = mlp->loss_part; G.correct_part = mlp->correct_part;
-    G.stride = mlp->gpart_stride; G.num_data = num_data; G.n_slices = slices; G.batch = mlp->batch;
-    rc = sgmcmc_step_indirect_parts(L, A_geometry, (const sgmcmc_step_args*)dev_args, &G,
-                                    S->capture_stream);
+  for (int i = 0; i < n_ring; ++i) {
+    unsigned char* slot = S->pinned + (int64_t)i * slot_bytes;
+    sgmcmc_mlp_args m = *mlp;
+    m.args_src = slot;
+    m.args_dst = dev_args;
+    m.args_bytes = (int32_t)sizeof(sgmcmc_step_args);
+    m.idx = reinterpret_cast<const int64_t*>(slot + sizeof(sgmcmc_step_args));
+    err = hipStreamBeginCapture(S->capture_stream, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) return (int)err;
+    rc = sgmcmc_mlp_fwdbwd(&m, S->capture_stream);
+    if (!rc)
+      rc = sgmcmc_step_indirect_parts(L, A_geometry, (const sgmcmc_step_args*)dev_args, &G,
+                                      S->capture_stream);
+    err = hipStreamEndCapture(S->capture_stream, &S->graphs[i]);
+    if (rc) return rc;
+    if (err != hipSuccess) return (int)err;
+    err = hipGraphInstantiate(&S->execs[i], S->graphs[i], nullptr, nullptr, 0);
+    if (err != hipSuccess) return (int)err;
   }
-  err = hipStreamEndCapture(S->capture_stream, &S->graph);
-  if (rc) return rc;
-  if (err != hipSuccess) return (int)err;
-  err = hipGraphInstantiate(&S->exec, S->graph, nullptr, nullptr, 0);
-  if (err != hipSuccess) return (int)err;
   *out = S;
   return 0;
 }
@@ -436,7 +487,7 @@ int sgmcmc_dense_stepper_step(sgmcmc_dense_stepper* S, const sgmcmc_step_args* A
   const int i = (int)(S->k % (uint64_t)S->n_ring);
   ++S->k;
   hipError_t err;
-  if (S->used[i]) {
+  if (S->used[i]) {  // the replay that last read this slot must have finished
     err = hipEventSynchronize(S->events[i]);
     if (err != hipSuccess) return (int)err;
   }
@@ -444,22 +495,23 @@ int sgmcmc_dense_stepper_step(sgmcmc_dense_stepper* S, const sgmcmc_step_args* A
   memcpy(slot, A, sizeof(sgmcmc_step_args));
   memcpy(slot + sizeof(sgmcmc_step_args), idx_host, 8 * (size_t)S->batch);
   hipStream_t s = (hipStream_t)stream;
-  err = hipMemcpyAsync(S->dev_args, slot, sizeof(sgmcmc_step_args) + 8 * (size_t)S->batch,
-                       hipMemcpyHostToDevice, s);
-  if (err != hipSuccess) return (int)err;
-  err = hipEventRecord(S->events[i], s);
+  err = hipGraphLaunch(S->execs[i], s);
   if (err != hipSuccess) return (int)err;
   S->used[i] = 1;
-  return (int)hipGraphLaunch(S->exec, s);
+  return (int)hipEventRecord(S->events[i], s);
 }
 
 int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S) {
   if (!S) return 0;
-  if (S->exec) (void)hipGraphExecDestroy(S->exec);
-  if (S->graph) (void)hipGraphDestroy(S->graph);
-  for (int i = 0; i < S->n_ring; ++i) (void)hipEventDestroy(S->events[i]);
+  for (int i = 0; i < S->n_ring; ++i) {
+    if (S->execs && S->execs[i]) (void)hipGraphExecDestroy(S->execs[i]);
+    if (S->graphs && S->graphs[i]) (void)hipGraphDestroy(S->graphs[i]);
+    (void)hipEventDestroy(S->events[i]);
+  }
   if (S->capture_stream) (void)hipStreamDestroy(S->capture_stream);
   delete[] S->events;
+  delete[] S->graphs;
+  delete[] S->execs;
   delete[] S->used;
   delete S;
   return 0;

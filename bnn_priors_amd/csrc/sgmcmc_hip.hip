@@ -456,6 +456,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel_parts(sgmcmc_layout L,
   step_body<T, KIND, VEC, ITEMS, true>(L, A, G);
 }
 
+template <typename T, int KIND, bool VEC, int ITEMS>
+__global__ __launch_bounds__(kThreads) void step_kernel_parts_val(sgmcmc_layout L, sgmcmc_step_args A,
+                                                                  GradParts G) {
+  step_body<T, KIND, VEC, ITEMS, true>(L, A, G);
+}
+
 // ------------------------------------------------------------------ per-segment finalize
 // Sums a segment's chunk partials in a fixed order (thread t takes chunks t, t+256, ...;
 // then a fixed LDS tree) and applies the reference's scalar bookkeeping.
@@ -792,7 +798,8 @@ template <typename T, int KIND, bool VEC, int ITEMS>
 void launch_step_mode(const sgmcmc_layout& L, const sgmcmc_step_args& A, const sgmcmc_step_args* Ad,
                       const GradParts* G, hipStream_t s) {
   const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
-  if (G) hipLaunchKernelGGL((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
+  if (G && Ad) hipLaunchKernelGGL((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
+  else if (G) hipLaunchKernelGGL((step_kernel_parts_val<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A, *G);
   else if (Ad) hipLaunchKernelGGL((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
   else hipLaunchKernelGGL((step_kernel<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A);
 }
@@ -884,6 +891,20 @@ int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A
   const int rc = launch_step(L, A, Ad, &G, s);
   if (rc) return rc;
   launch_finalize(L, A, Ad, s);
+  return (int)hipGetLastError();
+}
+
+// by-value variant used by sgmcmc_dense_step_direct (csrc/mlp_hip.hip)
+int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
+                            const sgmcmc_grad_parts* P, void* stream) {
+  if (!P || !P->gpart || P->n_slices <= 0 || P->batch <= 0 || !(P->num_data > 0))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const GradParts G = {P->gpart, P->n_slices, P->stride, P->loss_part, P->correct_part, P->batch,
+                       P->num_data};
+  const int rc = launch_step(L, A, nullptr, &G, s);
+  if (rc) return rc;
+  launch_finalize(L, A, nullptr, s);
   return (int)hipGetLastError();
 }
 

@@ -77,8 +77,11 @@ class FusedDenseLeapfrog:
         return (i % 4 == 0 and h1 == h1b and h2 == h2b and h1 <= 64 and h2 <= 64 and o <= 16
                 and _hip.lib().sgmcmc_mlp_lds_bytes(i) <= 160 * 1024)
 
-    def __init__(self, potential, optimizer, X, Y, ring=8):
+    def __init__(self, potential, optimizer, X, Y, ring=8, direct=None):
         assert self.supported(potential, optimizer)
+        import os
+        # three direct launches with by-value arguments vs replaying a captured graph
+        self.direct = (os.environ.get("SGMCMC_DENSE_DIRECT", "1") == "1") if direct is None else direct
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.lib = _hip.lib()
         eng, dev = self.eng, optimizer.engine.device
@@ -117,7 +120,8 @@ class FusedDenseLeapfrog:
             gpart_stride=self.stride, off_W1=o[0], off_b1=o[1], off_W2=o[2], off_b2=o[3],
             off_W3=o[4], off_b3=o[5], batch=batch, in_features=W1.shape[1], hidden1=W1.shape[0],
             hidden2=W2.shape[0], out_features=W3.shape[0],
-            inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None)
+            inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None,
+            args_src=None, args_dst=None, args_bytes=0)
         st["param_ptrs"] = [p.data_ptr() for p in eng.params]
         self._bind_grads()
         eng.refresh(self.opt._preconditioners())
@@ -183,9 +187,13 @@ class FusedDenseLeapfrog:
         A = self._args(st["A"], metrics)
         if idx_ptr is None:
             idx_ptr = idx.__array_interface__["data"][0]
-        err = self.lib.sgmcmc_dense_stepper_step(st["handle"], A, idx_ptr, eng.stream())
+        if self.direct and batch <= 256:
+            err = self.lib.sgmcmc_dense_step_direct(eng.layout, st["mlp"], A, self.pot.N, idx_ptr,
+                                                    eng.stream())
+        else:
+            err = self.lib.sgmcmc_dense_stepper_step(st["handle"], A, idx_ptr, eng.stream())
         if err:
-            _hip.check(err, "sgmcmc_dense_stepper_step")
+            _hip.check(err, "sgmcmc_dense_step")
         eng._state_host = None
         eng.energy_ready = True
         if not metrics:

@@ -231,6 +231,12 @@ typedef struct {
   int32_t batch, in_features, hidden1, hidden2, out_features;
   float inv_softmax_temp;
   int64_t* trace; /* optional (else NULL): 9 clock64() stamps at the phase boundaries of workgroup 0 */
+  /* optional (else NULL): workgroup 0 copies args_bytes (multiple of 4, <= 1024) from args_src
+   * (typically pinned HOST memory, read over PCIe) to args_dst (device) so that later kernels of
+   * the same graph find the step's scalars in device memory without a separate copy node */
+  const void* args_src;
+  void* args_dst;
+  int32_t args_bytes;
 } sgmcmc_mlp_args;
 
 int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream);
@@ -248,14 +254,16 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
                              const sgmcmc_step_args* A_dev, void* stream);
 
 /* ---- native replay of the fused dense leapfrog step ------------------------------------- */
-/* A "stepper" owns a hipGraph of  mlp_fwdbwd -> step_indirect_parts (update + finalize)  captured on
- * an internal stream at creation, and a ring of pinned host slots.  One call to
+/* A "stepper" owns n_ring replicas of a hipGraph  mlp_fwdbwd -> step_indirect_parts (update +
+ * finalize), captured on an internal stream at creation, one per pinned host slot.  One call to
  * sgmcmc_dense_stepper_step per leapfrog step: copies *A (per-step scalars) and idx[batch] (row
- * indices) into the next slot, enqueues ONE async H2D copy of the slot to `dev_args` and the
- * graph launch on `stream`.  A slot is reused only after the copy that last read it has
- * executed (event wait), so the host may run ahead of the GPU by up to n_ring steps.
- * Memory is the caller's: dev_args (device, slot_bytes), pinned (host-pinned, n_ring*slot_bytes),
- * slot_bytes >= sizeof(sgmcmc_step_args) + 8*batch; mlp->idx must be dev_args + sizeof(step_args). */
+ * indices) into the next slot and launches that slot's replica on `stream`; the first kernel
+ * reads the slot straight from host memory (row indices) and forwards the scalars to `dev_args`,
+ * so there is no separate copy node.  A slot is reused only after the replay that read it has
+ * completed (event wait): the host may run ahead of the GPU by up to n_ring steps.
+ * Memory is the caller's: dev_args (device, >= sizeof(sgmcmc_step_args)), pinned (host-pinned,
+ * n_ring*slot_bytes), slot_bytes >= sizeof(sgmcmc_step_args) + 8*batch and a multiple of 8;
+ * mlp->idx and mlp->args_* are set per slot by the library. */
 typedef struct sgmcmc_dense_stepper sgmcmc_dense_stepper;
 int sgmcmc_dense_stepper_create(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
                                 const sgmcmc_step_args* A_geometry, double num_data,
@@ -264,6 +272,15 @@ int sgmcmc_dense_stepper_create(const sgmcmc_layout* L, const sgmcmc_mlp_args* m
 int sgmcmc_dense_stepper_step(sgmcmc_dense_stepper* S, const sgmcmc_step_args* A,
                               const int64_t* idx_host, void* stream);
 int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S);
+
+/* The same leapfrog step as three DIRECT launches with every argument passed by value in
+ * the kernel-argument segment -- including the minibatch's row indices (int32, batch <=
+ * SGMCMC_MLP_MAX_INLINE) -- so there is no staging buffer, no copy and no graph: the runtime
+ * snapshots the arguments at launch time.  mlp->idx / args_* are ignored. */
+#define SGMCMC_MLP_MAX_INLINE 256
+int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
+                             const sgmcmc_step_args* A, double num_data, const int64_t* idx_host,
+                             void* stream);
 
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
