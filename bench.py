@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="densenet", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
-    ap.add_argument("--sweep-log2", type=int, default=26, help="flat-arena roofline point, log2(elements); 0 = skip")
+    ap.add_argument("--sweep-log2", type=int, default=28, help="flat-arena roofline point, log2(elements); 0 = skip")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture (for comparison)")
     return ap.parse_args()
