@@ -162,7 +162,7 @@ def main():
     eng = runner.optimizer.engine
     fused = runner._fused_dense() is not None
     batches = list(pool.index_batches()) if fused else list(pool)
-    path = ("fused-dense 3-kernel hipGraph" if fused else
+    path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
             "eager" if args.eager else "hipGraph of autograd fwd/bwd + fused sampler")
 
     def run(k, step):
