@@ -135,7 +135,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1:
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if distributed:   # one process per GPU under torch.distributed.run; "nccl" is RCCL on ROCm
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
@@ -174,15 +175,15 @@ def main():
 
     step = run(args.warmup, step)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if distributed:
         dist.barrier()
     t0 = time.perf_counter()
     step = run(args.steps, step)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -244,7 +245,7 @@ def main():
                           "(oracle/: reference-op-order torch-CPU loop, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -195,3 +195,30 @@ def test_fused_dense_step_agrees_with_autograd_graph_path():
             np.testing.assert_allclose(s0[k][1], s1[k][1], rtol=rt, atol=at, err_msg=k)
     for k in p0:
         torch.testing.assert_close(p0[k], p1[k], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dense_step_direct_and_graph_replica_modes_are_bit_identical(monkeypatch):
+    "three by-value launches vs replaying the captured per-slot graph replicas: same kernels, same bits"
+    outs = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("SGMCMC_DENSE_DIRECT", direct)
+        cfg = RC.CASES["VerletSGLDReject"]
+        dev = "cuda:0"
+        train, test, (x, y) = RC.make_data(dev)
+        model = RC.make_net(models, x, y, device=dev)
+        metrics = MemoryMetrics()
+        torch.manual_seed(RC.SEED)
+        runner = inference_reject.VerletSGLDRunnerReject(
+            model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+            temperature=cfg["temperature"], momentum=cfg["momentum"], reject_samples=True,
+            metrics_saver=metrics, model_saver=None, seed=RC.SEED, chain_id=0,
+            cycle_seed=RC.CYCLE_SEED, **RC.RUN_KW)
+        runner.run()
+        assert runner._fused.direct == (direct == "1")
+        outs.append((RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}))
+    (s0, p0), (s1, p1) = outs
+    for k in s0:
+        assert np.array_equal(s0[k][0], s1[k][0]) and np.array_equal(s0[k][1], s1[k][1]), k
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
