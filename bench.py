@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--sweep-log2", type=int, default=28, help="flat-arena roofline point, log2(elements); 0 = skip")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture (for comparison)")
+    ap.add_argument("--cudnn-benchmark", type=int, default=1,
+                    help="MIOpen find mode, as the reference sets it (experiments/train_bnn.py:29-31)")
+    ap.add_argument("--channels-last", type=int, default=0)
     return ap.parse_args()
 
 
@@ -145,7 +148,10 @@ def main():
 
     name, xshape, N, prior = WORKLOADS[args.workload]
     L = -(-N // 128)
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     model = make_model(args.workload, device)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     n_params = sum(p.numel() for p in model.parameters())
     pool = PoolSource(args.workload, 16, device, 1234 + rank)
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)

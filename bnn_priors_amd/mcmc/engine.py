@@ -41,7 +41,7 @@ def mh_uniform(seed, stream, draw):
 
 
 class Engine:
-    def __init__(self, param_groups, seed=None, chain_id=0):
+    def __init__(self, param_groups, seed=None, chain_id=0, chunk_elems=None, small_finalize=None):
         self.lib = _hip.lib()
         params = [p for g in param_groups for p in g["params"]]
         if not params:
@@ -67,6 +67,9 @@ class Engine:
         # chunks (one 16-byte item per thread) so that they still spread over many CUs.
         total_numel = sum(p.numel() for p in params)
         C = self.chunk = _hip.CHUNK_SMALL if total_numel <= (1 << 20) else _hip.CHUNK
+        if chunk_elems is not None:      # explicit choice (tests exercise both geometries)
+            assert chunk_elems in (_hip.CHUNK, _hip.CHUNK_SMALL)
+            C = self.chunk = chunk_elems
         seg = np.zeros(self.n_seg, dtype=_hip.SEGMENT_DTYPE)
         chunk_rows, first, noise = [], 0, 0
         self.group_ranges = []
@@ -115,6 +118,8 @@ class Engine:
         self.hidden_keys = frozenset()   # state keys this sampler family does not have
         # few chunks: one workgroup finalizes all segments and also emits the energy total
         self.small_finalize = len(param_groups) == 1 and self.n_chunks <= 4096
+        if small_finalize is not None:
+            self.small_finalize = bool(small_finalize) and len(param_groups) == 1
 
     # ------------------------------------------------------------------ views
     def _view(self, arena, i):

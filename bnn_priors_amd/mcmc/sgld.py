@@ -38,7 +38,7 @@ class SGLD(torch.optim.Optimizer):
 
     def __init__(self, params, lr, num_data, momentum=0, temperature=1.,
                  rmsprop_alpha=0.99, rmsprop_eps=1e-8, raise_on_no_grad=True,
-                 raise_on_nan=False, *, seed=None, chain_id=0, grad_clamp=0.0):
+                 raise_on_nan=False, *, seed=None, chain_id=0, grad_clamp=0.0, **engine_options):
         assert lr >= 0 and num_data >= 0 and momentum >= 0 and temperature >= 0
         defaults = dict(lr=lr, num_data=num_data, momentum=momentum, rmsprop_alpha=rmsprop_alpha,
                         rmsprop_eps=rmsprop_eps, temperature=temperature)
@@ -46,7 +46,7 @@ class SGLD(torch.optim.Optimizer):
         self.raise_on_no_grad = raise_on_no_grad
         self.raise_on_nan = raise_on_nan
         self.grad_clamp = float(grad_clamp)
-        self._engine = Engine(self.param_groups, seed=seed, chain_id=chain_id)
+        self._engine = Engine(self.param_groups, seed=seed, chain_id=chain_id, **engine_options)
         for i, p in enumerate(self._engine.params):
             st = self.state[p] = SegState(self._engine, i)
             st['square_avg'] = self._engine.square_avg_view(i)

@@ -92,9 +92,27 @@ class VerletSGLD(SGLD):
 
     def _energy_kernel_args(self):
         g = self.param_groups[0]
-        if any(h['lr'] != g['lr'] for h in self.param_groups):
-            raise NotImplementedError("delta_energy with per-group learning rates")
         return g['num_data'], g.get('b^2h^2', g['lr'] / g['num_data'])
+
+    def _energy_total_per_group(self):
+        """several parameter groups (different lr): per-segment reductions on the device, the few
+        per-tensor products of verlet_sgld.py:32-47 on the host in double"""
+        eng = self._engine
+        dots = eng.segment_sums(1 if self._KIND == _hip.HMC else 2)
+        st = eng.fetch_state()
+        col = _hip.SEG_STATE_FIELDS.index("delta_energy")
+        total, i = 0., 0
+        for g in self.param_groups:
+            b2h2 = g.get('b^2h^2', g['lr'] / g['num_data'])
+            for p in g['params']:
+                if self._KIND == _hip.HMC:
+                    point = .5 * dots[i]
+                else:
+                    M = self.state[p].setdefault('preconditioner', 1.)
+                    point = (M ** 2 * g['num_data'] ** 2 * b2h2 / 8) * dots[i]
+                total += float(st[i, col]) + point
+                i += 1
+        return total
 
     @torch.no_grad()
     def delta_energy(self, prev_potential, potential) -> float:
@@ -108,8 +126,11 @@ class VerletSGLD(SGLD):
         eng = self._engine
         eng.refresh(self._preconditioners(), raise_on_no_grad=True)
         self._adopt_foreign_momentum()
-        n, b2h2 = self._energy_kernel_args()
-        total = eng.delta_energy_total(self._KIND, n, b2h2, self.grad_clamp)
+        if len(self.param_groups) > 1:
+            total = self._energy_total_per_group()
+        else:
+            n, b2h2 = self._energy_kernel_args()
+            total = eng.delta_energy_total(self._KIND, n, b2h2, self.grad_clamp)
         if isinstance(potential, torch.Tensor):
             potential = potential.item()
         return total + (potential - prev_potential) * num_data

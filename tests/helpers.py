@@ -71,4 +71,18 @@ def compare(rec, gold, name, rtol, atol, traj_rtol=None, traj_atol=None, u_eps=0
         m = np.isfinite(b)
         at = atol + (extra if k in ("mh_delta_energy", "mh_log_acc") else 0.0)
         np.testing.assert_allclose(a[m], b[m], rtol=rtol, atol=at, err_msg=f"{name}:{k}")
+    # accept/reject margins: reject <=> log(u) > log_acc.  The decision is only as exact as dE;
+    # report the smallest |log u - log_acc| and require it to exceed the tolerance applied to dE
+    margins = []
+    for u, la, de in zip(rec.get("mh_u", []), g["mh_log_acc"], g["mh_delta_energy"]):
+        if np.isfinite(u) and np.isfinite(la):
+            margins.append(abs(np.log(u) - la))
+    if margins:
+        T = max(S.SCENARIOS[name]["T"], 1e-12)
+        floor = (atol + extra + rtol * float(np.abs(g["mh_delta_energy"][np.isfinite(g["mh_delta_energy"])]).max())) / T
+        MARGINS[name] = (min(margins), floor)
+        assert min(margins) > floor, f"{name}: accept margin {min(margins):.3g} <= dE tolerance {floor:.3g}"
     return g
+
+
+MARGINS = {}

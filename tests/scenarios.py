@@ -80,7 +80,23 @@ def drive(opt, model, closure, cfg, hooks, record_every=4):
     params = list(model.parameters())
     rec = dict(theta=[], mom=[], rec_steps=[], delta_energy=[], prev_delta=[], est_temp=[],
                est_cfg=[], mh_delta_energy=[], mh_log_acc=[], mh_rejected=[], mh_step=[],
-               lr=[], loss=[])
+               lr=[], loss=[], mh_u=[])
+    # mirror of the spec's sweep counter (one value per sample_momentum / step sweep / M-H test)
+    # so that the M-H uniforms -- and with them the accept margins -- can be reported
+    from oracle.noise import mh_uniform
+    counter = [0]
+    real_call = hooks.call
+
+    def counted_call(purpose, fn, *a, **kw):
+        if purpose == "mh":
+            if cfg["T"] != 0:
+                rec["mh_u"].append(mh_uniform(SEED, 0, counter[0]))
+                counter[0] += 1
+            else:
+                rec["mh_u"].append(float("nan"))
+        else:
+            counter[0] += 1
+        return real_call(purpose, fn, *a, **kw)
 
     def snapshot(step):
         rec["rec_steps"].append(step)
@@ -102,7 +118,8 @@ def drive(opt, model, closure, cfg, hooks, record_every=4):
         for g in opt.param_groups:
             g["lr"] *= LR_DECAY
 
-    hooks.call("momentum", opt.sample_momentum)
+    call = counted_call
+    call("momentum", opt.sample_momentum)
     prev_loss = None
     for step in range(N_STEPS + 1):
         if step % MH_EVERY == 0:
@@ -110,13 +127,13 @@ def drive(opt, model, closure, cfg, hooks, record_every=4):
                 # SGLD with a=0 cannot compute metrics on a final step (reference bug,
                 # mcmc/sgld.py:132-137)
                 cm = not (kind == "sgld" and cfg["a"] == 0)
-                loss = hooks.call("step", opt.final_step, closure, calc_metrics=cm).item()
+                loss = call("step", opt.final_step, closure, calc_metrics=cm).item()
                 scalars(loss)
                 de = opt.delta_energy(prev_loss, loss)
                 if kind == "sgld":
                     rejected, log_acc = False, 0.0
                 else:
-                    rejected, log_acc = hooks.call("mh", opt.maybe_reject, de)
+                    rejected, log_acc = call("mh", opt.maybe_reject, de)
                 rec["mh_delta_energy"].append(de)
                 rec["mh_log_acc"].append(log_acc)
                 rec["mh_rejected"].append(bool(rejected))
@@ -125,14 +142,14 @@ def drive(opt, model, closure, cfg, hooks, record_every=4):
                 if step == N_STEPS:
                     break
             if kind == "hmc":
-                hooks.call("momentum", opt.sample_momentum)
+                call("momentum", opt.sample_momentum)
             if kind == "sgld":
-                prev_loss = hooks.call("step", opt.step, closure).item()
+                prev_loss = call("step", opt.step, closure).item()
             else:
-                prev_loss = hooks.call("step", opt.initial_step, closure, save_state=True).item()
+                prev_loss = call("step", opt.initial_step, closure, save_state=True).item()
             scalars(prev_loss)
         else:
-            loss = hooks.call("step", opt.step, closure).item()
+            loss = call("step", opt.step, closure).item()
             scalars(loss)
         decay()
         if step % record_every == 1:

@@ -55,16 +55,18 @@ def test_single_hip_runtime_in_process():
 NUMELS = [5, 4096, 1, 4097, 130, 12288, 64]
 
 
-def _setup(kind, dtype, a, T, numels=NUMELS, seed=4242, stream=2):
+def _setup(kind, dtype, a, T, numels=NUMELS, seed=4242, stream=2, **engine_options):
     mcmc = _mcmc()
     g = torch.Generator().manual_seed(11)
     params = [torch.nn.Parameter(torch.randn(n, generator=g, dtype=torch.float64).to(dtype).to(DEV))
               for n in numels]
     if kind == "hmc":
-        opt = mcmc.HMC(params, lr=0.02, num_data=7, raise_on_nan=False, seed=seed, chain_id=stream)
+        opt = mcmc.HMC(params, lr=0.02, num_data=7, raise_on_nan=False, seed=seed, chain_id=stream,
+                       **engine_options)
     else:
         cls = mcmc.VerletSGLD if kind == "verlet" else mcmc.SGLD
-        opt = cls(params, lr=0.02, num_data=7, momentum=a, temperature=T, seed=seed, chain_id=stream)
+        opt = cls(params, lr=0.02, num_data=7, momentum=a, temperature=T, seed=seed, chain_id=stream,
+                  **engine_options)
     npdt = np.float32 if dtype == torch.float32 else np.float64
     fa = FlatArena(numels, npdt)
     for s, p in enumerate(params):
@@ -254,3 +256,72 @@ def test_small_finalize_energy_total_equals_delta_energy():
             fast = opt.delta_energy_of_last_transition(0.25, 0.5)
             slow = opt.delta_energy(0.25, 0.5)
             assert fast == pytest.approx(slow, rel=1e-12, abs=1e-12), (kind, call)
+
+
+@pytest.mark.parametrize("chunk,small", [(4096, True), (4096, False), (1024, False)])
+@pytest.mark.parametrize("kind", ["verlet", "hmc"])
+def test_both_chunk_geometries_and_both_finalize_paths(kind, chunk, small):
+    """the 4096-element chunk layout (4 items per thread) and the multi-workgroup finalize +
+    separate delta_energy reduction are what big arenas use; force them on a small problem"""
+    a = 0.9 if kind == "verlet" else 1.0
+    params, opt, fa, g = _setup(kind, torch.float32, a, 1.0, numels=[5, 9000, 1, 4097, 12288],
+                                chunk_elems=chunk, small_finalize=small)
+    assert opt.engine.chunk == chunk and opt.engine.small_finalize == small
+    opt.sample_momentum()
+    fa.sample_momentum(1.0, 0.0, 4242, 0, stream=2)
+    _assert_state_bit_exact(params, opt, fa, what="after sample_momentum")
+    for step_i, (call, flags) in enumerate((("initial_step", FLAG_INITIAL | FLAG_SAVE), ("step", 0),
+                                            ("final_step", FLAG_FINAL))):
+        _set_grads(params, fa, g, torch.float32)
+        getattr(opt, call)()
+        grp = opt.param_groups[0]
+        sums = fa.step(kind, grad_v=grp['grad_v'], bhn=grp['bhn'], bh=grp['bh'],
+                       mom_decay=grp['mom_decay'], noise_std=grp['noise_std'], alpha=0.99, seed=4242,
+                       draw=step_i + 1, stream=2, flags=flags).copy()
+        _assert_state_bit_exact(params, opt, fa, what=call)
+        np.testing.assert_allclose(opt.engine.fetch_state()[:, :6], sums, rtol=1e-12, atol=1e-300)
+        # energy: per-tensor oracle formula from the sums
+        de = opt.delta_energy(0.5, 0.75)
+        st = opt.engine.fetch_state()
+        if kind == "verlet":
+            curv = np.array([(0.3 + 0.1 * s) ** 2 * 7 ** 2 * grp['b^2h^2'] / 8 for s in range(len(params))])
+            want = float(np.sum(st[:, 6] + curv * sums[:, 0])) + 0.25 * 7
+        else:
+            want = float(np.sum(st[:, 6] + 0.5 * sums[:, 4])) + 0.25 * 7
+        assert de == pytest.approx(want, rel=1e-11, abs=1e-11)
+
+
+def test_two_parameter_groups_match_per_tensor_oracle():
+    "param groups with different learning rates / momenta: one fused launch per group"
+    from oracle.noise import NoiseSource
+    from oracle.samplers import RefVerletSGLD
+    mcmc = _mcmc()
+    g = torch.Generator().manual_seed(21)
+    numels = [300, 5000, 17, 2048]
+    cpu = [torch.nn.Parameter(torch.randn(n, generator=g)) for n in numels]
+    dev = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in cpu]
+
+    def groups(ps):
+        return [dict(params=ps[:2], lr=0.02, momentum=0.9), dict(params=ps[2:], lr=0.005, momentum=0.5)]
+    ref = RefVerletSGLD(groups(cpu), lr=0.01, num_data=11, momentum=0.7, temperature=1.0,
+                        noise=NoiseSource(99, numels, stream=1))
+    hip = mcmc.VerletSGLD(groups(dev), lr=0.01, num_data=11, momentum=0.7, temperature=1.0, seed=99,
+                          chain_id=1)
+    assert not hip.engine.small_finalize
+    for i, (p, q) in enumerate(zip(cpu, dev)):
+        ref.state[p]['preconditioner'] = hip.state[q]['preconditioner'] = 0.4 + 0.2 * i
+    ref.sample_momentum()
+    hip.sample_momentum()
+    for call in ("initial_step", "step", "step", "final_step"):
+        for p, q in zip(cpu, dev):
+            p.grad = torch.randn(p.shape, generator=g)
+            q.grad = p.grad.to(DEV)
+        getattr(ref, call)()
+        getattr(hip, call)()
+        for p, q in zip(cpu, dev):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+            torch.testing.assert_close(hip.state[q]['momentum_buffer'].cpu(), ref.state[p]['momentum_buffer'],
+                                       rtol=2e-6, atol=2e-7)
+            for k in ("delta_energy", "prev_new_momentum_delta", "est_temperature", "est_config_temp"):
+                assert hip.state[q][k] == pytest.approx(ref.state[p][k], rel=2e-5, abs=1e-6), (call, k)
+    assert hip.delta_energy(0.1, 0.3) == pytest.approx(ref.delta_energy(0.1, 0.3), rel=2e-5)
