@@ -52,38 +52,39 @@ def parse():
     ap.add_argument("--cudnn-benchmark", type=int, default=1,
                     help="MIOpen find mode, as the reference sets it (experiments/train_bnn.py:29-31)")
     ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--samples", type=int, default=3, help="also time K full sample cycles (0 = skip)")
     return ap.parse_args()
 
 
 class PoolSource:
-    """Synthetic device-resident data set of ``n_pool`` minibatches, with the interface the
-    runner expects from its batch source (tensor batches for the exact-gradient pass, index
-    batches for the fused dense step)."""
+    """Synthetic device-resident data set of N rows with the interface the runner expects from
+    its batch source: tensor batches (exact-gradient pass of the generic path), index batches
+    (fused dense step), ``x`` / ``y`` (fused exact pass)."""
     fast = True
 
-    def __init__(self, workload, n_pool, device, seed):
+    def __init__(self, workload, n_rows, device, seed):
         _, xshape, _, _ = WORKLOADS[workload]
         g = torch.Generator(device=device).manual_seed(seed)
-        n = n_pool * 128
         if workload == "googleresnet":
-            self.x = torch.randn((n,) + xshape, generator=g, device=device)
+            self.x = torch.randn((n_rows,) + xshape, generator=g, device=device)
         else:
-            self.x = torch.rand((n,) + xshape, generator=g, device=device)
-        self.y = torch.randint(0, 10, (n,), generator=g, device=device)
-        self.n_pool = n_pool
+            self.x = torch.rand((n_rows,) + xshape, generator=g, device=device)
+        self.y = torch.randint(0, 10, (n_rows,), generator=g, device=device)
+        self.n_rows, self.n_batches = n_rows, -(-n_rows // 128)
 
     def __len__(self):
-        return self.n_pool
+        return self.n_batches
 
     def __iter__(self):
-        for b in range(self.n_pool):
+        for b in range(self.n_batches):
             yield self.x[128 * b:128 * (b + 1)], self.y[128 * b:128 * (b + 1)]
 
     def index_batches(self):
         import numpy as np
         from bnn_priors_amd.fused_dense import IndexBatch
-        for b in range(self.n_pool):
-            yield IndexBatch(np.arange(128 * b, 128 * (b + 1), dtype=np.int64), self.x, self.y), None
+        for b in range(self.n_batches):
+            idx = np.arange(128 * b, min(128 * (b + 1), self.n_rows), dtype=np.int64)
+            yield IndexBatch(idx, self.x, self.y), None
 
 
 def make_model(workload, device):
@@ -153,7 +154,7 @@ def main():
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
     n_params = sum(p.numel() for p in model.parameters())
-    pool = PoolSource(args.workload, 16, device, 1234 + rank)
+    pool = PoolSource(args.workload, N, device, 1234 + rank)   # the whole synthetic data set, in HBM
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
     runner = VerletSGLDRunnerReject(
@@ -169,6 +170,7 @@ def main():
     eng = runner.optimizer.engine
     fused = runner._fused_dense() is not None
     batches = list(pool.index_batches()) if fused else list(pool)
+    batches = [b for b in batches if len(b[0]) == 128]       # the L-th minibatch is ragged (N % 128)
     path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
             "eager" if args.eager else "hipGraph of autograd fwd/bwd + fused sampler")
 
@@ -209,6 +211,35 @@ def main():
         for _ in range(200):
             opt.step(calc_metrics=False)
         ktimes = eng.stop_kernel_timing()
+    samples = None
+    if args.samples > 0:
+        # one stored sample = L leapfrog steps + the exact full-data gradient + final_step + M-H test
+        # + initial_step (inference_reject.py:86-157); timed end to end, K times
+        all_b = list(pool.index_batches()) if fused else list(pool)
+        opt = runner.optimizer
+
+        def one_sample(step):
+            for i, (x, y) in enumerate(all_b):
+                step += 1
+                runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
+            step += 1
+            loss, log_prior, potential = runner._exact_model_potential_and_grad(pool)
+            opt.final_step(calc_metrics=True)
+            de = runner._delta_energy(potential)
+            de = de.item() if isinstance(de, torch.Tensor) else de
+            runner._initial_potential = potential.item()
+            opt.maybe_reject(de)
+            runner.scheduler.step()
+            opt.initial_step(calc_metrics=False, save_state=True)
+            return step
+
+        step = one_sample(step)          # untimed: first use of the ragged last minibatch etc.
+        torch.cuda.synchronize(device)
+        ts = time.perf_counter()
+        for _ in range(args.samples):
+            step = one_sample(step)
+        torch.cuda.synchronize(device)
+        samples = args.samples / (time.perf_counter() - ts)
     out = {
         "metric": "leapfrog steps/sec, VerletSGLDReject", "value": round(world * args.steps / dt, 2),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,6 +251,11 @@ def main():
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
                    "step_path": path},
     }
+    if samples is not None:
+        out["samples_per_sec"] = {"value": round(world * samples, 3), "per_chain": round(samples, 3),
+                                  "leapfrog_steps_per_sample": L,
+                                  "includes": "L leapfrog steps, exact full-data gradient pass "
+                                              "(N rows), final_step, M-H test, initial_step"}
     if rank == 0:
         if ktimes:
             chunks = ktimes[0][1]
@@ -239,7 +275,7 @@ def main():
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
-            cpu_batches = [(x.cpu(), y.cpu()) for x, y in pool]
+            cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]
             res = time_cpu_baseline(lambda: make_model(args.workload, "cpu"), cpu_batches,
                                     num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
                                     steps_per_cycle=L * 50, budget_s=args.cpu_budget)

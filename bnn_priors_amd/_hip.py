@@ -85,7 +85,8 @@ class MlpArgs(ctypes.Structure):
                 ("hidden1", ctypes.c_int32), ("hidden2", ctypes.c_int32),
                 ("out_features", ctypes.c_int32), ("inv_softmax_temp", ctypes.c_float),
                 ("trace", ctypes.c_void_p), ("args_src", ctypes.c_void_p),
-                ("args_dst", ctypes.c_void_p), ("args_bytes", ctypes.c_int32)]
+                ("args_dst", ctypes.c_void_p), ("args_bytes", ctypes.c_int32),
+                ("grad_scale", ctypes.c_float)]
 
 
 EXPORTS = {
@@ -131,6 +132,10 @@ EXPORTS = {
     "sgmcmc_dense_step_direct": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(MlpArgs),
                                                 ctypes.POINTER(StepArgs), ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_accumulate_parts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -71,7 +71,7 @@ __device__ __forceinline__ void mlp_fwdbwd_body(const sgmcmc_mlp_args& P, const 
   const int slice = blockIdx.x;
   const int row0 = slice * ROWS;
   float* __restrict__ gp = P.gpart + (int64_t)slice * P.gpart_stride;
-  const float invB = 1.0f / (float)P.batch;
+  const float invB = P.grad_scale > 0.f ? P.grad_scale : 1.0f / (float)P.batch;
   int tp = 0;
 #define MLP_TRACE() do { if (P.trace && blockIdx.x == 0 && tid == 0) P.trace[tp] = (int64_t)clock64(); ++tp; } while (0)
   MLP_TRACE();
@@ -413,6 +413,39 @@ int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
   G.gpart = mlp->gpart; G.loss_part = mlp->loss_part; G.correct_part = mlp->correct_part;
   G.stride = mlp->gpart_stride; G.num_data = num_data; G.n_slices = slices; G.batch = mlp->batch;
   return sgmcmc_step_parts_value(L, A, &G, s);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void accumulate_parts_kernel(const float* __restrict__ gpart,
+                                                               int n_slices, int64_t stride,
+                                                               double* __restrict__ acc,
+                                                               float* __restrict__ out, int64_t n,
+                                                               const float* __restrict__ loss_part,
+                                                               const float* __restrict__ correct_part,
+                                                               double* __restrict__ stats, int first) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) {
+    double a = first ? 0.0 : acc[j];
+    for (int s = 0; s < n_slices; ++s) a += (double)gpart[(int64_t)s * stride + j];
+    acc[j] = a;
+    if (out) out[j] = (float)a;
+  }
+  if (stats && j == 0) {
+    double l = first ? 0.0 : stats[0], c = first ? 0.0 : stats[1];
+    for (int s = 0; s < n_slices; ++s) { l += (double)loss_part[s]; c += (double)correct_part[s]; }
+    stats[0] = l; stats[1] = c;
+  }
+}
+}  // namespace
+
+int sgmcmc_accumulate_parts(const float* gpart, int n_slices, int64_t stride, double* acc,
+                            float* out_f32, int64_t n, const float* loss_part,
+                            const float* correct_part, double* stats, int first, void* stream) {
+  if (!gpart || !acc || n_slices <= 0 || n <= 0 || n > stride) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(accumulate_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, gpart, n_slices, stride, acc, out_f32, n, loss_part,
+                     correct_part, stats, first);
+  return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------- native stepper

@@ -1045,9 +1045,14 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
   const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch, num_data};
   if (A_dev)
     hipLaunchKernelGGL(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
-  else
-    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data,
-                       (int)((flags & SGMCMC_CALC_METRICS) != 0), G);
+  else {
+    const int calc = (int)((flags & SGMCMC_CALC_METRICS) != 0);
+    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc, G);
+    if (calc) {  // no sampler launch follows to finish the log-prior: do it here
+      hipLaunchKernelGGL(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
+      hipLaunchKernelGGL(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
+    }
+  }
   return (int)hipGetLastError();
 }
 

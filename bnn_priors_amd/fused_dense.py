@@ -85,6 +85,7 @@ class FusedDenseLeapfrog:
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.lib = _hip.lib()
         eng, dev = self.eng, optimizer.engine.device
+        self.X_source = X      # identity of the data set this stepper gathers from
         self.X = X.to(dev, torch.float32).contiguous().view(X.shape[0], -1)
         self.Y = Y.to(dev, torch.int64).contiguous()
         self.lin = _dense_layers(potential.model)
@@ -121,7 +122,7 @@ class FusedDenseLeapfrog:
             off_W3=o[4], off_b3=o[5], batch=batch, in_features=W1.shape[1], hidden1=W1.shape[0],
             hidden2=W2.shape[0], out_features=W3.shape[0],
             inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None,
-            args_src=None, args_dst=None, args_bytes=0)
+            args_src=None, args_dst=None, args_bytes=0, grad_scale=0.0)
         st["param_ptrs"] = [p.data_ptr() for p in eng.params]
         self._bind_grads()
         eng.refresh(self.opt._preconditioners())
@@ -164,6 +165,60 @@ class FusedDenseLeapfrog:
             for p, g in zip(params, self.static_grads):
                 p.grad = g
             self.eng._seg_dirty = True
+
+    # ------------------------------------------------------------------ exact full-data gradient
+    MEGA = 2048   # rows per launch of the fused kernel in the full-data pass (128 workgroups)
+
+    def exact(self):
+        """g <- grad[-log_prior/N] + grad[-sum_i log p(y_i|x_i)/N] over the WHOLE device-resident
+        data set (reference: inference_reject.py:18-33, one autograd pass per minibatch): the fused
+        forward/backward kernel on mega-batches of 2048 rows, fp64 accumulation across them, then
+        the prior gradient and log-density.  Returns (loss, log_prior, potential) as 0-d tensors."""
+        eng, dev, lib = self.eng, self.eng.device, self.lib
+        n_data = self.X.shape[0]
+        ex = getattr(self, "_exact_state", None)
+        if ex is None:
+            S = self.MEGA // _hip.MLP_ROWS
+            ex = self._exact_state = dict(
+                gpart=torch.zeros(S * self.stride, device=dev), loss_part=torch.zeros(S, device=dev),
+                corr_part=torch.zeros(S, device=dev),
+                acc=torch.zeros(self.stride, dtype=torch.float64, device=dev),
+                gsum=torch.zeros(self.stride, device=dev),
+                stats=torch.zeros(2, dtype=torch.float64, device=dev))
+        W1, b1, W2, b2, W3, b3 = eng.params
+        o = self.offs
+        stream = eng.stream()
+        self._bind_grads()
+        eng.refresh(self.opt._preconditioners())
+        in_f = W1.shape[1]
+        for start in range(0, n_data, self.MEGA):
+            mb = min(self.MEGA, n_data - start)
+            A = _hip.MlpArgs(
+                X=self.X.data_ptr() + 4 * start * in_f, Y=self.Y.data_ptr() + 8 * start, idx=None,
+                W1=W1.data_ptr(), b1=b1.data_ptr(), W2=W2.data_ptr(), b2=b2.data_ptr(),
+                W3=W3.data_ptr(), b3=b3.data_ptr(), gpart=ex["gpart"].data_ptr(),
+                loss_part=ex["loss_part"].data_ptr(), correct_part=ex["corr_part"].data_ptr(),
+                gpart_stride=self.stride, off_W1=o[0], off_b1=o[1], off_W2=o[2], off_b2=o[3],
+                off_W3=o[4], off_b3=o[5], batch=mb, in_features=in_f, hidden1=W1.shape[0],
+                hidden2=W2.shape[0], out_features=W3.shape[0],
+                inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None,
+                args_src=None, args_dst=None, args_bytes=0, grad_scale=1.0 / self.pot.N)
+            _hip.check(lib.sgmcmc_mlp_fwdbwd(ctypes.byref(A), stream), "sgmcmc_mlp_fwdbwd")
+            last = start + mb >= n_data
+            _hip.check(lib.sgmcmc_accumulate_parts(
+                ex["gpart"].data_ptr(), -(-mb // _hip.MLP_ROWS), self.stride, ex["acc"].data_ptr(),
+                ex["gsum"].data_ptr() if last else None, self.stride, ex["loss_part"].data_ptr(),
+                ex["corr_part"].data_ptr(), ex["stats"].data_ptr(), int(start == 0), stream),
+                "sgmcmc_accumulate_parts")
+        # prior gradient + log-density on top of the accumulated likelihood gradient (one "slice")
+        _hip.check(lib.sgmcmc_grad_reduce_prior(
+            ctypes.byref(eng.layout), ex["gsum"].data_ptr(), 1, self.stride, ex["loss_part"].data_ptr(),
+            ex["corr_part"].data_ptr(), 1, self.pot.N, _hip.CALC_METRICS, None, stream),
+            "sgmcmc_grad_reduce_prior")
+        eng._touch()
+        loss = ex["stats"][0] / self.pot.N
+        log_prior = eng.scalars[2].clone()
+        return loss, log_prior, loss - log_prior / self.pot.N
 
     # ------------------------------------------------------------------ replay
     def replay(self, idx, metrics=False, idx_ptr=None):

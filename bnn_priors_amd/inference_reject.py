@@ -40,6 +40,9 @@ class VerletSGLDRunnerReject(SGLDRunner):
     def _exact_model_potential_and_grad(self, batches):
         """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N], accumulated over the
         whole loader (inference_reject.py:18-33); see potential.py."""
+        fused = self._fused_dense()
+        if fused is not None and getattr(batches, "fast", False) and batches.x is fused.X_source:
+            return fused.exact()
         return self._potential().exact(batches)
 
     def leapfrog(self, step, x, y, last_of_epoch):

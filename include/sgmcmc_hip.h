@@ -237,6 +237,9 @@ typedef struct {
   const void* args_src;
   void* args_dst;
   int32_t args_bytes;
+  /* > 0: dL/dlogits is scaled by this instead of 1/batch.  The exact full-data gradient
+   * (inference_reject.py:18-33) is the sum over mega-batches of  -sum_i log p_i / N : scale = 1/N */
+  float grad_scale;
 } sgmcmc_mlp_args;
 
 int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream);
@@ -281,6 +284,14 @@ int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S);
 int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
                              const sgmcmc_step_args* A, double num_data, const int64_t* idx_host,
                              void* stream);
+
+/* acc[j] <- (first ? 0 : acc[j]) + sum_{s<n_slices} gpart[s*stride + j]   for j < n  (fp64
+ * accumulator, fixed order); out_f32[j] <- (float)acc[j] when out_f32 != NULL;
+ * stats[0] += sum loss_part, stats[1] += sum correct_part (zeroed first when `first`).
+ * Accumulates the mega-batches of the exact full-data gradient pass. */
+int sgmcmc_accumulate_parts(const float* gpart, int n_slices, int64_t stride, double* acc,
+                            float* out_f32, int64_t n, const float* loss_part,
+                            const float* correct_part, double* stats, int first, void* stream);
 
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,

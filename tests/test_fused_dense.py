@@ -83,3 +83,36 @@ def test_mlp_fwdbwd_identity_index_and_determinism():
     for u, v in zip(a[0], b[0]):
         assert torch.equal(u, v)
     assert a[1] == b[1]
+
+
+def test_fused_exact_gradient_pass_matches_autograd():
+    """full-data gradient through the fused kernel (mega-batches, fp64 accumulation) vs the
+    reference formulation through autograd (inference_reject.py:18-33)"""
+    import sys
+    import runner_cases as RC
+    from bnn_priors_amd import inference_reject, models
+    from bnn_priors_amd.storage import MemoryMetrics
+    cfg = RC.CASES["VerletSGLDReject"]
+    g = torch.Generator().manual_seed(9)
+    n = 5000                                  # 2 full mega-batches + a ragged one
+    x = torch.rand(n, 784, generator=g).to(DEV)
+    y = torch.randint(0, 10, (n,), generator=g).to(DEV)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=128, shuffle=True)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:0], y[:0]), batch_size=128)
+    model = RC.make_net(models, x.cpu(), y.cpu(), device=DEV)
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+        temperature=1.0, momentum=0.9, metrics_saver=MemoryMetrics(), seed=1, **RC.RUN_KW)
+    runner.optimizer = runner._make_optimizer(runner._params)
+    fused = runner._fused_dense()
+    assert fused is not None
+    loss_f, lp_f, pot_f = fused.exact()
+    got = [p.grad.clone() for p in runner._params]
+    loss_a, lp_a, pot_a = runner._potential().exact(runner._batches())
+    want = [p.grad.clone() for p in runner._params]
+    assert loss_f.item() == pytest.approx(float(loss_a), rel=2e-6)
+    assert lp_f.item() == pytest.approx(float(lp_a), rel=1e-9)
+    assert pot_f.item() == pytest.approx(float(pot_a), rel=2e-6)
+    for a, b in zip(got, want):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 3e-6 * scale + 1e-10
