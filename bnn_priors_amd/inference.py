@@ -132,7 +132,7 @@ class SGLDRunner:
                  sample_epochs, learning_rate=1e-2, skip=1, metrics_skip=1, temperature=1.,
                  data_mult=1., momentum=0., sampling_decay=True, grad_max=1e6, cycles=1,
                  precond_update=None, metrics_saver=None, model_saver=None, reject_samples=False,
-                 *, seed=None, chain_id=0):
+                 *, seed=None, chain_id=0, use_graph=True):
         self.model, self.dataloader, self.dataloader_test = model, dataloader, dataloader_test
         assert warmup_epochs >= 0
         assert sample_epochs >= 0
@@ -158,6 +158,11 @@ class SGLDRunner:
         self.reject_samples = reject_samples
         self.seed, self.chain_id = seed, chain_id
         self._device = self._params[0].device
+        # ``use_graph``: run ordinary steps through a captured hipGraph (graphed.py) or, for the
+        # dense classifier on a device-resident data set, the fused 3-launch step (fused_dense.py)
+        self.use_graph = use_graph
+        self._graphed = None
+        self._fused = None
 
     # ------------------------------------------------------------------ factories
     def _sampler_kwargs(self):
@@ -192,6 +197,66 @@ class SGLDRunner:
             self._batch_source = _BatchSource(self.dataloader, self._device)
             return self._batch_source
 
+    def _fused_dense(self):
+        """the 3-kernel fused step (fused_dense.py) when the model is the dense classifier and the
+        data set is device resident; None otherwise"""
+        if not self.use_graph or self._fused is False:
+            return None
+        if self._fused is None:
+            from .fused_dense import FusedDenseLeapfrog
+            src = self._batches()
+            pot = self._potential()
+            if (getattr(src, "fast", False) and pot.fast
+                    and FusedDenseLeapfrog.supported(pot, self.optimizer)):
+                self._fused = FusedDenseLeapfrog(pot, self.optimizer, src.x, src.y)
+            else:
+                self._fused = False
+                return None
+        return self._fused
+
+    def _hot_batches(self):
+        "minibatches of one epoch for the leapfrog loop: by index when the fused step can gather them"
+        src = self._batches()
+        if self._fused_dense() is not None and hasattr(src, "index_batches"):
+            return src.index_batches()
+        return iter(src)
+
+    def _graph_for(self, x, y):
+        """the captured graph if this step can use it (fused potential, matching batch shape)"""
+        if not self.use_graph or self._graphed is False:
+            return None
+        if self._graphed is None:
+            pot = self._potential()
+            if not pot.fast or pot.leftover or len(self.optimizer.param_groups) != 1:
+                self._graphed = False
+                return None
+            from .graphed import GraphedLeapfrog
+            self._graphed = GraphedLeapfrog(pot, self.optimizer, x, y)
+        return self._graphed if self._graphed.matches(x, y) else None
+
+    @staticmethod
+    def _tensors_of(x, y):
+        return x.materialize() if y is None else (x, y)
+
+    def _fast_plain_step(self, x, y, store):
+        """Gradient + ordinary sampler ``step`` through the fastest available path.  Returns
+        (handled, r, x, y): ``handled`` False means the caller runs the eager path on the returned
+        tensors; on metric steps ``r`` = dict(loss, acc, log_prior, potential, energy) of floats."""
+        by_index = y is None          # an IndexBatch from _BatchSource.index_batches()
+        if by_index and self._fused_dense() is None:
+            x, y = x.materialize()
+            by_index = False
+        graphed = self._fused_dense() if by_index else self._graph_for(x, y)
+        if graphed is None:
+            return False, None, x, y
+        r = (graphed.replay(x.idx, metrics=store, idx_ptr=x.ptr) if by_index
+             else graphed.replay(x, y, metrics=store))
+        if store:
+            if r["nonfinite"]:
+                raise ValueError("Potential is NaN")
+            r["potential"] = r["loss"] - r["log_prior"] / self.eff_num_data
+        return True, r, x, y
+
     # ------------------------------------------------------------------ the run
     def run(self, progressbar=False):
         "inference.py:110-187"
@@ -206,12 +271,11 @@ class SGLDRunner:
             for epoch in range(self.epochs_per_cycle):
                 for g in self.optimizer.param_groups:
                     g['temperature'] = 0. if epoch < self.descent_epochs else self.temperature
-                for i, (x, y) in enumerate(self._batches()):
+                for i, (x, y) in enumerate(self._hot_batches()):
                     step += 1
                     store_metrics = (i == 0 or step % self.metrics_skip == 0)
                     initial_step = (step == 0 or (i == 0 and self._is_sampling_epoch(epoch - 1)))
-                    self.step(step, x.detach(), y.detach(), store_metrics=store_metrics,
-                              initial_step=initial_step)
+                    self.step(step, x, y, store_metrics=store_metrics, initial_step=initial_step)
                 if self.precond_update is not None and epoch % self.precond_update == 0:
                     self.optimizer.update_preconditioner()
                 self._check_finite()
@@ -269,6 +333,16 @@ class SGLDRunner:
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
         "inference.py:225-249"
+        handled, r, x, y = self._fast_plain_step(x, y, store_metrics)
+        if handled:
+            lr = self.optimizer.param_groups[0]["lr"]
+            if lr_decay:
+                self.scheduler.step()
+            if store_metrics:
+                self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],   # quirk 6
+                                   potential=r["potential"], acc=r["acc"], lr=lr,
+                                   corresponds_to_sample=initial_step)
+            return r and r["loss"], r and r["acc"], None
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store_metrics)
         self.optimizer.step(calc_metrics=store_metrics)
         lr = self.optimizer.param_groups[0]["lr"]
@@ -325,6 +399,24 @@ class VerletSGLDRunner(SGLDRunner):
                                **self._sampler_kwargs())
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
+        if i != 0 and not initial_step:
+            handled, r, x, y = self._fast_plain_step(x, y, store_metrics)
+            if handled:
+                lr = self.optimizer.param_groups[0]["lr"]
+                delta_energy = None
+                if store_metrics:
+                    # quirk 13: the reference passes `loss` where a potential is expected
+                    delta_energy = self.optimizer.delta_energy_from_total(
+                        r["energy"], self._initial_potential, r["loss"])
+                    self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],
+                                       potential=r["potential"], acc=r["acc"], lr=lr,
+                                       delta_energy=delta_energy,
+                                       total_energy=self._total_energy + delta_energy,
+                                       rejected=None, corresponds_to_sample=initial_step)
+                if lr_decay:
+                    self.scheduler.step()
+                return r and r["loss"], r and r["acc"], delta_energy
+        x, y = self._tensors_of(x, y)
         # an M-H point or the very first step always stores metrics (see below)
         want = store_metrics or i == 0 or initial_step
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, want)

@@ -20,17 +20,12 @@ def _f(v):
 
 
 class VerletSGLDRunnerReject(SGLDRunner):
-    def __init__(self, *a, cycle_seed=None, use_graph=True, **kw):
+    def __init__(self, *a, cycle_seed=None, **kw):
         """``cycle_seed``: None reproduces the reference (a fresh non-deterministic
         shuffle seed per cycle, inference_reject.py:72); an int pins cycle c's seed to
-        ``cycle_seed + c`` so that runs (and parity tests) are repeatable.
-        ``use_graph``: replay ordinary leapfrog steps from a captured hipGraph (graphed.py)
-        when the model allows it; results are identical to the eager path."""
+        ``cycle_seed + c`` so that runs (and parity tests) are repeatable."""
         super().__init__(*a, **kw)
         self.cycle_seed = cycle_seed
-        self.use_graph = use_graph
-        self._graphed = None
-        self._fused = None
 
     def _make_optimizer(self, params):
         return mcmc.VerletSGLD(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
@@ -49,31 +44,23 @@ class VerletSGLDRunnerReject(SGLDRunner):
         """One minibatch leapfrog step: stochastic gradient, fused sampler transition,
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
         store = (step % self.metrics_skip) == 0
-        opt, N = self.optimizer, self.eff_num_data
-        by_index = y is None          # an IndexBatch from _BatchSource.index_batches()
-        if by_index and self._fused_dense() is None:
-            x, y = x.materialize()
-            by_index = False
-        graphed = self._fused_dense() if by_index else self._graph_for(x, y)
-        if graphed is not None:
-            r = (graphed.replay(x.idx, metrics=store, idx_ptr=x.ptr) if by_index
-                 else graphed.replay(x, y, metrics=store))
+        opt = self.optimizer
+        handled, r, x, y = self._fast_plain_step(x, y, store)
+        if handled:
             acc = None
             if store:
-                if r["nonfinite"]:
-                    raise ValueError("Potential is NaN")
-                potential = r["loss"] - r["log_prior"] / N
                 delta_energy = opt.delta_energy_from_total(r["energy"], self._initial_potential,
-                                                           potential)
+                                                           r["potential"])
                 self.store_metrics(i=step, loss=r["loss"], log_prior=r["log_prior"],
-                                   potential=potential, acc=r["acc"], lr=opt.param_groups[0]["lr"],
-                                   corresponds_to_sample=False, delta_energy=delta_energy,
+                                   potential=r["potential"], acc=r["acc"],
+                                   lr=opt.param_groups[0]["lr"], corresponds_to_sample=False,
+                                   delta_energy=delta_energy,
                                    total_energy=self._total_energy + delta_energy)
                 acc = r["acc"]
             if not last_of_epoch:
                 self.scheduler.step()
             elif acc is None:                                # quirk 5: the sample row logs it
-                acc = self._potential().accuracy(*(x.materialize() if by_index else (x, y)))
+                acc = self._potential().accuracy(*self._tensors_of(x, y))
             return acc
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
         opt.step(calc_metrics=store)
@@ -97,43 +84,6 @@ class VerletSGLDRunnerReject(SGLDRunner):
         has already reduced it; samplers without that shortcut use ``delta_energy``"""
         fn = getattr(self.optimizer, "delta_energy_of_last_transition", self.optimizer.delta_energy)
         return fn(self._initial_potential, potential)
-
-    def _fused_dense(self):
-        """the 3-kernel fused step (fused_dense.py) when the model is the dense classifier and the
-        data set is device resident; None otherwise"""
-        if not self.use_graph or self._fused is False:
-            return None
-        if self._fused is None:
-            from .fused_dense import FusedDenseLeapfrog
-            src = self._batches()
-            pot = self._potential()
-            if (getattr(src, "fast", False) and pot.fast
-                    and FusedDenseLeapfrog.supported(pot, self.optimizer)):
-                self._fused = FusedDenseLeapfrog(pot, self.optimizer, src.x, src.y)
-            else:
-                self._fused = False
-                return None
-        return self._fused
-
-    def _hot_batches(self):
-        "minibatches of one epoch for the leapfrog loop: by index when the fused step can gather them"
-        src = self._batches()
-        if self._fused_dense() is not None and hasattr(src, "index_batches"):
-            return src.index_batches()
-        return iter(src)
-
-    def _graph_for(self, x, y):
-        """the captured graph if this step can use it (fused potential, matching batch shape)"""
-        if not self.use_graph or self._graphed is False:
-            return None
-        if self._graphed is None:
-            pot = self._potential()
-            if not pot.fast or pot.leftover or len(self.optimizer.param_groups) != 1:
-                self._graphed = False
-                return None
-            from .graphed import GraphedLeapfrog
-            self._graphed = GraphedLeapfrog(pot, self.optimizer, x, y)
-        return self._graphed if self._graphed.matches(x, y) else None
 
     def begin(self):
         """optimizer, scheduler, exact initial gradient, momentum draw and the first
