@@ -15,7 +15,8 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
-SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip"), os.path.join(_HERE, "csrc", "mlp_hip.hip")]
+# one translation unit: sgmcmc_hip.hip #includes mlp_hip.inc (they share the finalize body)
+SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")]
 SOURCE = SOURCES[0]
 
 ABI_VERSION = 2
@@ -28,6 +29,7 @@ F32, F64 = 0, 1
 VERLET, HMC, SGLD = 0, 1, 2
 INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM, SMALL_FINALIZE = 1, 2, 4, 8, 16, 32, 64
 WITH_LOG_PRIOR = 128
+DEFER_FINALIZE = 256
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T = 0, 1, 2, 3
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
@@ -131,7 +133,10 @@ EXPORTS = {
     "sgmcmc_dense_stepper_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "sgmcmc_dense_step_direct": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(MlpArgs),
                                                 ctypes.POINTER(StepArgs), ctypes.c_double,
-                                                ctypes.c_void_p, ctypes.c_void_p]),
+                                                ctypes.c_void_p, ctypes.POINTER(StepArgs),
+                                                ctypes.c_void_p]),
+    "sgmcmc_finalize": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
+                                       ctypes.c_void_p]),
     "sgmcmc_accumulate_parts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -178,7 +183,8 @@ def build(verbose=False):
     """hipcc cross-compile for gfx950 (works without a GPU)."""
     import subprocess
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, *SOURCES, "-o", LIB_PATH]
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-I", os.path.join(_HERE, "csrc"), *SOURCES,
+           "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -591,9 +591,9 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
 __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
   // wave w owns segments seg_begin + w, + 4, ...: its 64 lanes stride over the segment's chunk
   // partials (all loads independent), then a fixed shuffle tree; lane 0 does the bookkeeping.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
   const bool with_lp = (A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS);
-  for (int seg = A.seg_begin + wave; seg < A.seg_end; seg += kThreads / 64) {
+  for (int seg = A.seg_begin + wave; seg < A.seg_end; seg += n_waves) {
     const sgmcmc_segment s = L.segs[seg];
     const int64_t n = seg_chunks(L, s);
     double S[SGMCMC_NSUMS + 1] = {0, 0, 0, 0, 0, 0, 0};
@@ -637,10 +637,10 @@ __global__ __launch_bounds__(kThreads) void finalize_step_kernel_indirect(sgmcmc
   finalize_step_body(L, A);
 }
 
-__global__ __launch_bounds__(kThreads) void finalize_small_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+__global__ void finalize_small_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
   finalize_small_body(L, A);
 }
-__global__ __launch_bounds__(kThreads) void finalize_small_kernel_indirect(sgmcmc_layout L,
+__global__ void finalize_small_kernel_indirect(sgmcmc_layout L,
                                                                            const sgmcmc_step_args* Ap) {
   const sgmcmc_step_args A = *Ap;
   finalize_small_body(L, A);
@@ -874,6 +874,7 @@ int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_
 
 void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
                      hipStream_t s) {
+  if (A->flags & SGMCMC_DEFER_FINALIZE) return;  // the caller runs it later (sgmcmc_finalize)
   const bool small = A->flags & SGMCMC_SMALL_FINALIZE;
   const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)), block(kThreads);
   if (Ad) {
@@ -931,7 +932,7 @@ int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A
   return (int)hipGetLastError();
 }
 
-// by-value variant used by sgmcmc_dense_step_direct (csrc/mlp_hip.hip)
+// by-value variant used by sgmcmc_dense_step_direct (csrc/mlp_hip.inc)
 int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
                             const sgmcmc_grad_parts* P, void* stream) {
   if (!P || !P->gpart || P->n_slices <= 0 || P->batch <= 0 || !(P->num_data > 0))
@@ -942,6 +943,14 @@ int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
   const int rc = launch_step(L, A, nullptr, &G, s);
   if (rc) return rc;
   launch_finalize(L, A, nullptr, s);
+  return (int)hipGetLastError();
+}
+
+int sgmcmc_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+  if (!L || !A || A->seg_end <= A->seg_begin) return (int)hipErrorInvalidValue;
+  sgmcmc_step_args B = *A;
+  B.flags &= ~(uint32_t)SGMCMC_DEFER_FINALIZE;
+  launch_finalize(L, &B, nullptr, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
@@ -1065,3 +1074,6 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 }
 
 }  // extern "C"
+
+// the fused dense-net kernels share the finalize body above (deferred finalize rides in their launch)
+#include "mlp_hip.inc"

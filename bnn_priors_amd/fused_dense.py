@@ -5,7 +5,7 @@ element-wise priors; reference models/dense_nets.py:48-67) a leapfrog step is
 
     [one async copy: per-step scalars + the minibatch's row indices]
     mlp_fwdbwd_kernel       fused forward + backward on the matrix cores, rows gathered by
-                            index from the device-resident data set      (csrc/mlp_hip.hip)
+                            index from the device-resident data set      (csrc/mlp_hip.inc)
     prior_kernel_indirect   fixed-order sum of the per-slice partial gradients + prior
                             gradient (+ log-prior partials on metric steps)
     step_kernel_indirect    fused sampler transition (noise, momentum, position, RMSprop, dots)
@@ -96,7 +96,7 @@ class FusedDenseLeapfrog:
         self.static_grads = [self.g_flat[o:o + p.numel()].view(p.shape)
                              for o, p in zip(self.offs, eng.params)]
         self.nbytes_args = ctypes.sizeof(_hip.StepArgs)
-        self._ring, self._k = ring, 0
+        self._ring, self._k, self._pp = ring, 0, 0
         self._by_batch = {}
         self._host_report = torch.empty(eng.report.shape, dtype=torch.float64).pin_memory()
 
@@ -134,6 +134,7 @@ class FusedDenseLeapfrog:
             st["dev"].data_ptr(), st["pinned"].data_ptr(), self._ring, slot_bytes,
             ctypes.byref(handle)), "sgmcmc_dense_stepper_create")
         st["handle"] = handle
+        st["App"] = [self._args(None, False, advance=False), self._args(None, False, advance=False)]
         torch.cuda.synchronize(dev)
         return st
 
@@ -239,13 +240,22 @@ class FusedDenseLeapfrog:
         self._bind_grads()
         if eng._seg_dirty or eng._precond_dirty:
             eng.refresh(self.opt._preconditioners())
-        A = self._args(st["A"], metrics)
         if idx_ptr is None:
             idx_ptr = idx.__array_interface__["data"][0]
         if self.direct and batch <= 256:
+            # ping-pong argument structs: the previous step's may still be pending
+            self._pp ^= 1
+            A = self._args(st["App"][self._pp], metrics)
+            if not metrics and eng.small_finalize:
+                A.flags |= _hip.DEFER_FINALIZE      # its bookkeeping rides in the NEXT launch
+            pending, eng.pending = eng.pending, None
             err = self.lib.sgmcmc_dense_step_direct(eng.layout, st["mlp"], A, self.pot.N, idx_ptr,
-                                                    eng.stream())
+                                                    pending, eng.stream())
+            if A.flags & _hip.DEFER_FINALIZE:
+                eng.pending = A
         else:
+            eng.flush()
+            A = self._args(st["A"], metrics)
             err = self.lib.sgmcmc_dense_stepper_step(st["handle"], A, idx_ptr, eng.stream())
         if err:
             _hip.check(err, "sgmcmc_dense_step")

@@ -217,6 +217,18 @@ class Engine:
                 row["prior_kind"], row["prior_loc"], row["prior_scale"], row["prior_df"] = sp
         self._seg_dirty = True
 
+    # ------------------------------------------------------------------ deferred finalize
+    # The fused dense step leaves a transition's per-segment bookkeeping pending (it is not an
+    # input of the next gradient evaluation) and runs it inside its NEXT launch; anything else
+    # that touches the partials / state calls flush() first.
+    pending = None
+
+    def flush(self):
+        A = self.pending
+        if A is not None:
+            self.pending = None
+            _hip.check(self.lib.sgmcmc_finalize(self.layout, A, self.stream()), "sgmcmc_finalize")
+
     # ------------------------------------------------------------------ launches
     def next_draw(self):
         d = self.draw
@@ -239,12 +251,14 @@ class Engine:
 
     def step_indirect(self, A_host, args_dev_ptr):
         "enqueue the fused transition with its scalars read from device memory (graph capture)"
+        self.flush()
         _hip.check(self.lib.sgmcmc_step_indirect(ctypes.byref(self.layout), ctypes.byref(A_host),
                                                  ctypes.c_void_p(args_dev_ptr), self.stream()),
                    "sgmcmc_step_indirect")
         self._touch()
 
     def step(self, gi, kind, flags, draw, **scalars):
+        self.flush()
         if flags & _hip.SAVE_STATE:
             self.ensure_prev()
         A = self.make_args(gi, kind, flags, draw, **scalars)
@@ -291,16 +305,19 @@ class Engine:
         return out
 
     def sample_momentum(self, std, keep, draw):
+        self.flush()
         _hip.check(self.lib.sgmcmc_sample_momentum(ctypes.byref(self.layout), std, keep, self.seed,
                                                    self.chain_id, draw, self.stream()),
                    "sgmcmc_sample_momentum")
         self.momentum_ready = True
 
     def restore(self, restore_momentum):
+        self.flush()
         _hip.check(self.lib.sgmcmc_restore(ctypes.byref(self.layout), int(restore_momentum), 0,
                                            self.stream()), "sgmcmc_restore")
 
     def delta_energy_total(self, kind, num_data, b2h2, grad_clamp=0.0):
+        self.flush()
         _hip.check(self.lib.sgmcmc_delta_energy(ctypes.byref(self.layout), kind, num_data, b2h2,
                                                 grad_clamp, 0, self.stream()), "sgmcmc_delta_energy")
         self._touch()
@@ -308,15 +325,18 @@ class Engine:
 
     def last_transition_energy(self):
         "scalars[3]: sum_s(delta_energy_s + point_energy_s) left by the last small-finalize launch"
+        self.flush()
         return self.scalars[3]
 
     def segment_sums(self, which):
+        self.flush()
         _hip.check(self.lib.sgmcmc_segment_sum(ctypes.byref(self.layout), which, 0, self.stream()),
                    "sgmcmc_segment_sum")
         self._touch()
         return self.fetch_state()[:, _hip.SEG_STATE_FIELDS.index("aux")].copy()
 
     def prior_grad(self, num_data, calc_log_prob):
+        self.flush()
         _hip.check(self.lib.sgmcmc_prior_grad(ctypes.byref(self.layout), float(num_data),
                                               int(bool(calc_log_prob)), 0, self.stream()),
                    "sgmcmc_prior_grad")
@@ -325,9 +345,11 @@ class Engine:
 
     def log_prior_total(self):
         "sum of the fused priors' log-densities from the last prior_grad(calc_log_prob=True)"
+        self.flush()
         return self.scalars[2]
 
     def nonfinite_seen(self, reset=True):
+        self.flush()
         flag = self.scalars[1].item() != 0.0
         if flag and reset:
             self.scalars[1].zero_()
@@ -336,6 +358,7 @@ class Engine:
     def fetch_state(self):
         "[n_seg, 12] float64 host copy of the per-segment scalars (one sync, cached)"
         if self._state_host is None:
+            self.flush()
             self._state_host = self.state_dev.cpu().numpy().reshape(self.n_seg, -1)
         return self._state_host
 

@@ -54,6 +54,9 @@ enum {
   SGMCMC_SMALL_FINALIZE = 64, /* few chunks: one workgroup finalizes all segments and leaves
                                  scalars[3] = sum_s(delta_energy_s + point_energy_s) for the
                                  gradient / momentum of THIS transition */
+  SGMCMC_DEFER_FINALIZE = 256, /* launch only the update kernel; the per-segment bookkeeping is run
+                                  later by sgmcmc_finalize or inside the next sgmcmc_dense_step_direct
+                                  (it is not an input of the next gradient evaluation) */
   SGMCMC_WITH_LOG_PRIOR = 128 /* with SMALL_FINALIZE + CALC_METRICS: partials[.][6] holds the
                                  fused priors' log-density partials (sgmcmc_grad_reduce_prior):
                                  finish state[s].aux and scalars[2] in the same launch */
@@ -214,7 +217,7 @@ int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob
 /* ---- fused dense classifier (ClassificationDenseNet, models/dense_nets.py:48-67) ---------- */
 /* Forward + backward of -(1/B) sum_i log softmax(net(x_i) / T)[y_i] for
  * net = Linear(in,h1)-ReLU-Linear(h1,h2)-ReLU-Linear(h2,out), fp32, in ONE launch
- * (csrc/mlp_hip.hip).  Rows are gathered as X[idx[b]], Y[idx[b]] (idx == NULL: b itself).
+ * (csrc/mlp_hip.inc).  Rows are gathered as X[idx[b]], Y[idx[b]] (idx == NULL: b itself).
  * Workgroup s writes its 16 rows' PARTIAL gradients to gpart + s*gpart_stride at the given
  * per-tensor offsets, and loss_part[s] = sum of its rows' losses, correct_part[s] = #correct.
  * Limits: in % 4 == 0, h1,h2 <= 64, out <= 16, LDS(in) <= 160 KiB. */
@@ -283,7 +286,15 @@ int sgmcmc_dense_stepper_destroy(sgmcmc_dense_stepper* S);
 #define SGMCMC_MLP_MAX_INLINE 256
 int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
                              const sgmcmc_step_args* A, double num_data, const int64_t* idx_host,
-                             void* stream);
+                             const sgmcmc_step_args* A_pending, void* stream);
+/* A_pending != NULL: the bookkeeping of an EARLIER transition launched with
+ * SGMCMC_DEFER_FINALIZE (small-finalize layouts only) is executed by one extra workgroup of this
+ * call's gradient kernel, i.e. concurrently with the forward/backward and before this call's
+ * update kernel.  If A->flags has SGMCMC_DEFER_FINALIZE this call's own bookkeeping is left
+ * pending in turn; otherwise it is launched as usual. */
+
+/* The per-segment bookkeeping of a transition that was launched with SGMCMC_DEFER_FINALIZE. */
+int sgmcmc_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream);
 
 /* acc[j] <- (first ? 0 : acc[j]) + sum_{s<n_slices} gpart[s*stride + j]   for j < n  (fp64
  * accumulator, fixed order); out_f32[j] <- (float)acc[j] when out_f32 != NULL;

@@ -1,4 +1,4 @@
-"""Fused dense-classifier kernel (csrc/mlp_hip.hip) against a plain PyTorch fp32
+"""Fused dense-classifier kernel (csrc/mlp_hip.inc) against a plain PyTorch fp32
 reference of the same op: gradients of mean cross-entropy of a 3-layer ReLU MLP."""
 import ctypes
 
