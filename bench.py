@@ -53,6 +53,9 @@ def parse():
                     help="MIOpen find mode, as the reference sets it (experiments/train_bnn.py:29-31)")
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--samples", type=int, default=3, help="also time K full sample cycles (0 = skip)")
+    ap.add_argument("--inference", default="VerletSGLDReject",
+                    choices=["VerletSGLDReject", "HMCReject", "SGLDReject"],
+                    help="runner, as experiments/train_bnn.py:223-234 names them (headline: VerletSGLDReject)")
     return ap.parse_args()
 
 
@@ -144,7 +147,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    from bnn_priors_amd.inference_reject import VerletSGLDRunnerReject
+    from bnn_priors_amd.inference_reject import runner_class
     from bnn_priors_amd.storage import MemoryMetrics
 
     name, xshape, N, prior = WORKLOADS[args.workload]
@@ -157,12 +160,13 @@ def main():
     pool = PoolSource(args.workload, N, device, 1234 + rank)   # the whole synthetic data set, in HBM
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
-    runner = VerletSGLDRunnerReject(
+    hmc = args.inference == "HMCReject"
+    runner = runner_class(args.inference)(
         model=model, dataloader=loader, dataloader_test=empty_test, epochs_per_cycle=50,
-        warmup_epochs=45, sample_epochs=5, learning_rate=0.01, skip=1, metrics_skip=10,
-        temperature=1.0, momentum=0.994, sampling_decay="cosine", cycles=60, precond_update=1,
-        metrics_saver=MemoryMetrics(), model_saver=None, reject_samples=True,
-        seed=1234, chain_id=rank)
+        warmup_epochs=50 if hmc else 45, sample_epochs=0 if hmc else 5, learning_rate=0.01 if not hmc else 1e-4,
+        skip=1, metrics_skip=10, temperature=1.0, momentum=1.0 if hmc else 0.994,
+        sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
+        model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank)
     # the exact initial gradient over the synthetic pool stands in for the full-data pass
     runner._batch_source = pool
     runner.use_graph = not args.eager
@@ -241,11 +245,11 @@ def main():
         torch.cuda.synchronize(device)
         samples = args.samples / (time.perf_counter() - ts)
     out = {
-        "metric": "leapfrog steps/sec, VerletSGLDReject", "value": round(world * args.steps / dt, 2),
+        "metric": f"leapfrog steps/sec, {args.inference}", "value": round(world * args.steps / dt, 2),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name} VerletSGLDReject batch=128 N={N} (L={L} steps/epoch) "
+        "config": {"workload": f"{name} {args.inference} batch=128 N={N} (L={L} steps/epoch) "
                                f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip=10 prior={prior}",
                    "params": n_params, "tensors": len(list(model.parameters())),
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
