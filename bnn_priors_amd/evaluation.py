@@ -17,7 +17,8 @@ import math
 
 import torch
 
-__all__ = ("evaluate_model", "predictive_tables", "ensemble_across_chains", "ensemble_metrics")
+__all__ = ("evaluate_model", "predictive_tables", "ensemble_across_chains", "ensemble_metrics",
+           "gather_samples")
 
 
 def _labels_of(dataloader):
@@ -115,3 +116,29 @@ def ensemble_across_chains(lps, acc, group=None):
         m_glob, s_glob, count = m_local, s_local, torch.tensor(float(x.shape[0]), dtype=x.dtype)
     lme = m_glob + s_glob.log() - count.log()
     return lme[..., 0], lme[..., 1:]
+
+
+def gather_samples(samples, dst=0, group=None):
+    """Collect every chain's stored samples (``runner.get_samples()``: name -> [E_c, ...]) on rank
+    ``dst`` as name -> [sum_c E_c, ...], chain by chain -- what a single ``samples.pt`` of an
+    8-chain run contains (reference: one file per chain, experiments/run_experiment.sh:15-34).
+    One all_gather per tensor over RCCL (gloo in the CPU tests); returns None on other ranks."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return samples
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out = {}
+    for name in sorted(samples):
+        t = samples[name].contiguous()
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n, group=group)
+        counts = [int(c.item()) for c in counts]
+        pad = max(counts)
+        buf = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        buf[:t.shape[0]] = t
+        parts = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        if rank == dst:
+            out[name] = torch.cat([p[:c] for p, c in zip(parts, counts)])
+    return out if rank == dst else None

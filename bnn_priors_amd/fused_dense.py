@@ -54,7 +54,7 @@ def _dense_layers(model):
     lin = [net[0], net[2], net[4]]
     if not all(isinstance(net[i], nn.ReLU) for i in (1, 3)):
         return None
-    from .models.layers import Linear
+    from .models.nets import Linear
     for l in lin:
         if not isinstance(l, Linear) or l.bias_prior is None:
             return None

@@ -20,7 +20,7 @@ import torch
 
 from . import mcmc
 from .evaluation import evaluate_model
-from .utils import get_cosine_schedule
+from .schedule import get_cosine_schedule
 
 __all__ = ("SGLDRunner", "VerletSGLDRunner", "HMCRunner")
 

@@ -41,6 +41,8 @@ def mh_uniform(seed, stream, draw):
 
 
 class Engine:
+    _instances = 0
+
     def __init__(self, param_groups, seed=None, chain_id=0, chunk_elems=None, small_finalize=None):
         self.lib = _hip.lib()
         params = [p for g in param_groups for p in g["params"]]
@@ -60,7 +62,11 @@ class Engine:
         self.n_seg = len(params)
         self.index = {id(p): i for i, p in enumerate(params)}
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+            # reproducible under torch.manual_seed WITHOUT consuming the global generator (the
+            # reference draws nothing at optimizer construction; the runners' shuffles must stay
+            # aligned with it): the process seed mixed with a per-process instance counter
+            Engine._instances += 1
+            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + Engine._instances * 0xD1B54A32D192ED03)
         self.seed, self.chain_id, self.draw = int(seed) & (2 ** 64 - 1), int(chain_id), 0
 
         # ---- tables.  Chunk size is a property of the layout: small models get 1024-element

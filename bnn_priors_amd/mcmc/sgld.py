@@ -77,13 +77,14 @@ class SGLD(torch.optim.Optimizer):
         eng = self._engine
         for i, p in enumerate(eng.params):
             st = self.state[p]
-            mb = dict.get(st, 'momentum_buffer')
-            if mb is None:
-                continue
-            view = eng.momentum_view(i)
-            if mb.data_ptr() != view.data_ptr():
-                view.copy_(mb)
-                st['momentum_buffer'] = view
+            for key, view_of in (('momentum_buffer', eng.momentum_view), ('square_avg', eng.square_avg_view)):
+                t = dict.get(st, key)
+                if t is None:
+                    continue
+                view = view_of(i)
+                if t.data_ptr() != view.data_ptr():     # e.g. after load_state_dict
+                    view.copy_(t)
+                    dict.__setitem__(st, key, view)
 
     def _check_nan(self):
         if self.raise_on_nan and self._engine.nonfinite_seen():

@@ -17,10 +17,43 @@ from torch import nn
 
 from .. import prior
 from .base import ClassificationModel, RegressionModel
-from .layers import Conv2d, Linear
 
-__all__ = ("LinearPrior", "Conv2dPrior", "DenseNet", "ClassificationDenseNet",
+__all__ = ("Linear", "Conv2d", "LinearPrior", "Conv2dPrior", "DenseNet", "ClassificationDenseNet",
            "ClassificationConvNet", "ResNet", "Reshape")
+
+
+
+class _PriorBacked(nn.Module):
+    """A layer whose ``weight`` / ``bias`` are produced by Prior modules (``weight_prior`` /
+    ``bias_prior``), which keeps the reference's parameter names ``<idx>.weight_prior.p`` and
+    ``<idx>.bias_prior.p`` (reference: models/layers.py:5-46)."""
+
+    def __init__(self, weight_prior, bias_prior):
+        super().__init__()
+        self.weight_prior, self.bias_prior = weight_prior, bias_prior
+
+    weight = property(lambda self: self.weight_prior())
+    bias = property(lambda self: None if self.bias_prior is None else self.bias_prior())
+
+
+class Linear(_PriorBacked):
+    def __init__(self, weight_prior, bias_prior=None):
+        super().__init__(weight_prior, bias_prior)
+        self.out_features, self.in_features = weight_prior.p.shape
+
+    def forward(self, x):
+        return nn.functional.linear(x, self.weight, self.bias)
+
+
+class Conv2d(_PriorBacked):
+    def __init__(self, weight_prior, bias_prior=None, stride=1, padding=0, dilation=1, groups=1):
+        super().__init__(weight_prior, bias_prior)
+        self.out_channels, cin, kh, kw = weight_prior.p.shape
+        self.in_channels, self.kernel_size, self.groups = cin * groups, (kh, kw), groups
+        self.conv_args = (stride, padding, dilation, groups)
+
+    def forward(self, x):
+        return nn.functional.conv2d(x, self.weight, self.bias, *self.conv_args)
 
 
 def _default_scaling(std, dim):

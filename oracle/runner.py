@@ -35,7 +35,7 @@ def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metr
 
 
 def _setup(make_model, batches, num_data, lr, momentum, temperature, steps_per_cycle):
-    from bnn_priors_amd.utils import get_cosine_schedule  # a pure function of i (utils.py:5-10)
+    from bnn_priors_amd.schedule import get_cosine_schedule  # a pure function of i (utils.py:5-10)
     model = make_model()
     opt = RefVerletSGLD(list(model.parameters()), lr=lr, num_data=num_data, momentum=momentum,
                         temperature=temperature)

@@ -69,3 +69,28 @@ def test_chain_streams_are_disjoint():
     a = noise.normals(1234, 0, 5, 0, 0, 4096)
     b = noise.normals(1234, 1, 5, 0, 0, 4096)
     assert abs(float((a * b).mean())) < 0.06 and not (a == b).any()
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bnn_priors_amd.evaluation import gather_samples
+        E = 2 + rank
+        samples = {"a.p": torch.full((E, 3, 2), float(rank)), "steps": torch.arange(E) + 10 * rank}
+        got = gather_samples(samples)
+        if rank == 0:
+            torch.save(got, out)
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_samples_gloo_world2(tmp_path):
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["a.p"].shape == (5, 3, 2)
+    assert got["a.p"][:2].eq(0).all() and got["a.p"][2:].eq(1).all()
+    assert got["steps"].tolist() == [0, 1, 10, 11, 12]
