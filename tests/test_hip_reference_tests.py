@@ -157,6 +157,10 @@ def test_verlet_accept_prob_closed_form(n_samples=10):
 
 
 def _distribution_checks(opt, n_vars, n_dim, mean, std_eff, temp_scale, check_kinetic=True):
+    """The reference's probabilistic criteria (Anderson-Darling normality at 15 %, KS p >= 0.3 for
+    the parameters and for the per-tensor temperatures) as pass flags -- a CORRECT sampler passes
+    each only 70-85 % of the time -- plus moment checks at 4 standard errors, which are both
+    sharper (2.5 % on variance / temperatures) and essentially never fail for a correct sampler."""
     params = np.empty(n_vars * n_dim)
     kin, cfg = np.empty(n_vars), np.empty(n_vars)
     for i, (p, st) in enumerate(opt.state.items()):
@@ -171,6 +175,13 @@ def _distribution_checks(opt, n_vars, n_dim, mean, std_eff, temp_scale, check_ki
     ok["config_temp"] = scipy.stats.ks_1samp(cfg, chi2, method='exact').pvalue >= 0.3
     if check_kinetic:
         ok["kinetic_temp"] = scipy.stats.ks_1samp(kin, chi2, method='exact').pvalue >= 0.3
+    n = params.size
+    assert abs(params.mean() - mean) < 4 * std_eff / math.sqrt(n), ("mean", params.mean())
+    assert abs(params.var() / std_eff ** 2 - 1) < 4 * math.sqrt(2 / n), ("variance", params.var())
+    t_err = 4 * temp_scale * math.sqrt(2 / n)
+    assert abs(cfg.mean() - temp_scale) < t_err, ("config temperature", cfg.mean())
+    if check_kinetic:
+        assert abs(kin.mean() - temp_scale) < t_err, ("kinetic temperature", kin.mean())
     return ok
 
 
@@ -180,7 +191,8 @@ def _run_verlet_preservation(seed, n_vars=50, n_dim=1000, n_samples=200, mh_freq
         torch.manual_seed(seed)
         mean, std, T = 1., 2., 3 / 4
         model = models.GaussianModel(N=n_vars, D=n_dim, mean=mean, std=std).to(DEV)
-        opt = mcmc.VerletSGLD(model.parameters(), lr=1 / 32, num_data=1, momentum=0.9, temperature=T)
+        opt = mcmc.VerletSGLD(model.parameters(), lr=1 / 32, num_data=1, momentum=0.9, temperature=T,
+                              seed=1000 + seed)
         model.sample_all_priors()
         with torch.no_grad():
             for p in model.parameters():
@@ -212,16 +224,16 @@ def test_verlet_distribution_preservation():
     """test_verlet_sgld.py:58-146.  The four probabilistic assertions pass jointly
     ~1/3 of the time for a CORRECT sampler (reference's own note, :215-219), and the
     noise stream here is Philox, not mt19937, so the reference's hand-picked seed does
-    not transfer: require the acceptance bar on every seed and every individual
-    assertion to hold on a plausible fraction of 6 seeds."""
+    not transfer: require the acceptance bar and 4-sigma moment checks on every seed, and every
+    individual probabilistic assertion to hold on at least one of 6 (fixed) seeds."""
     passes = {}
     for seed in range(6):
         acc, ok = _run_verlet_preservation(seed)
         assert acc > 0.6, acc  # "Was 0.73 at commit 56988f7"
         for k, v in ok.items():
             passes[k] = passes.get(k, 0) + int(v)
-    # expected pass rates 0.85 / 0.7 / 0.7 / 0.7; P(<=1 of 6 | p=0.7) = 1.1 %
-    assert all(v >= 2 for v in passes.values()), passes
+    # expected pass rates 0.85 / 0.7 / 0.7 / 0.7 per seed; P(0 of 6 | p = 0.7) = 0.07 %
+    assert all(v >= 1 for v in passes.values()), passes
 
 
 def test_hmc_distribution_preservation(n_vars=50, n_dim=1000, n_samples=100, resample=4):
@@ -232,7 +244,7 @@ def test_hmc_distribution_preservation(n_vars=50, n_dim=1000, n_samples=100, res
         torch.manual_seed(122 + seed)
         mean, std = 1., 2.
         model = models.GaussianModel(N=n_vars, D=n_dim, mean=mean, std=std).to(DEV)
-        opt = mcmc.HMC(model.parameters(), lr=1 / 32, num_data=1)
+        opt = mcmc.HMC(model.parameters(), lr=1 / 32, num_data=1, seed=2000 + seed)
         model.sample_all_priors()
         for _, st in opt.state.items():
             st['preconditioner'] = (torch.rand(()).item() + 0.2) / math.sqrt(std)
@@ -258,7 +270,7 @@ def test_hmc_distribution_preservation(n_vars=50, n_dim=1000, n_samples=100, res
         for k, v in _distribution_checks(opt, n_vars, n_dim, mean, std, 1.0).items():
             passes[k] = passes.get(k, 0) + int(v)
     assert min(accs) > 0.6, accs  # "Was 0.65 at commit 56988f7"
-    assert all(v >= 2 for v in passes.values()), passes
+    assert all(v >= 1 for v in passes.values()), passes
 
 
 def test_sgld_distribution_preservation(n_vars=50, n_dim=1000, n_samples=200):
@@ -269,7 +281,8 @@ def test_sgld_distribution_preservation(n_vars=50, n_dim=1000, n_samples=200):
         torch.manual_seed(123 + seed)
         mean, std, T = 1., 2., 3 / 4
         model = models.GaussianModel(N=n_vars, D=n_dim, mean=mean, std=std).to(DEV)
-        opt = mcmc.SGLD(model.parameters(), lr=1 / 512, num_data=1, momentum=0.9, temperature=T)
+        opt = mcmc.SGLD(model.parameters(), lr=1 / 512, num_data=1, momentum=0.9, temperature=T,
+                        seed=3000 + seed)
         model.sample_all_priors()
         with torch.no_grad():
             for p in model.parameters():
@@ -282,7 +295,7 @@ def test_sgld_distribution_preservation(n_vars=50, n_dim=1000, n_samples=200):
         for k, v in _distribution_checks(opt, n_vars, n_dim, mean, std * T ** .5, T,
                                          check_kinetic=False).items():
             passes[k] = passes.get(k, 0) + int(v)
-    assert all(v >= 2 for v in passes.values()), passes
+    assert all(v >= 1 for v in passes.values()), passes
 
 
 def test_errors_match_reference():
