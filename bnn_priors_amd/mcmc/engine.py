@@ -40,6 +40,20 @@ def mh_uniform(seed, stream, draw):
     return (2 * (x0 >> 9) + 1) * 2.0 ** -24
 
 
+def _dense(t):
+    "non-overlapping and dense: sorted by stride, every stride is the product of the smaller extents"
+    if t.is_contiguous():
+        return True
+    expect = 1
+    for size, stride in sorted(zip(t.shape, t.stride()), key=lambda z: z[1]):
+        if size == 1:
+            continue
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 class Engine:
     _instances = 0
 
@@ -129,9 +143,11 @@ class Engine:
 
     # ------------------------------------------------------------------ views
     def _view(self, arena, i):
+        "the tensor's slice of a state arena, with the parameter's own (dense) strides"
         p = self.params[i]
         off = int(self.seg_host[i]["first_chunk"]) * self.chunk
-        return arena[off:off + p.numel()].view(p.shape)
+        flat = arena[off:off + p.numel()]
+        return flat.view(p.shape) if p.is_contiguous() else flat.as_strided(p.shape, p.stride())
 
     def momentum_view(self, i):
         return self._view(self.m, i)
@@ -177,12 +193,17 @@ class Engine:
         if ptrs != self._ptr_cache:
             unaligned = False
             for i, p in enumerate(self.params):
-                if not p.is_contiguous():
-                    raise RuntimeError("parameters must be contiguous")
+                # the kernels are element-wise over STORAGE order: any non-overlapping, dense
+                # layout works (contiguous, channels_last, ...) provided theta and its gradient
+                # share it; the state arenas mirror it through _view
+                if not _dense(p):
+                    raise RuntimeError("parameters must be dense (non-overlapping) tensors")
                 g = p.grad
-                if g is not None and (not g.is_contiguous() or g.dtype != self.dtype
+                if g is not None and (g.stride() != p.stride() or g.dtype != self.dtype
                                       or g.device != self.device):
-                    p.grad = g = g.to(device=self.device, dtype=self.dtype).contiguous()
+                    fixed = torch.empty_like(p, memory_format=torch.preserve_format)
+                    fixed.copy_(g)
+                    p.grad = g = fixed
                     ptrs[i] = (p.data_ptr(), g.data_ptr())
                 th, gp = ptrs[i]
                 unaligned |= bool(th % 16) or bool(gp % 16)

@@ -325,3 +325,28 @@ def test_two_parameter_groups_match_per_tensor_oracle():
             for k in ("delta_energy", "prev_new_momentum_delta", "est_temperature", "est_config_temp"):
                 assert hip.state[q][k] == pytest.approx(ref.state[p][k], rel=2e-5, abs=1e-6), (call, k)
     assert hip.delta_energy(0.1, 0.3) == pytest.approx(ref.delta_energy(0.1, 0.3), rel=2e-5)
+
+
+def test_channels_last_parameters_are_supported():
+    "dense non-contiguous layouts: theta, grad and the state views share the storage order"
+    mcmc = _mcmc()
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(16, 8, 3, 3, generator=g)
+    p_cl = torch.nn.Parameter(w.clone().to(DEV).contiguous(memory_format=torch.channels_last))
+    p_ct = torch.nn.Parameter(w.clone().to(DEV))
+    assert not p_cl.is_contiguous()
+    outs = []
+    for p in (p_cl, p_ct):
+        opt = mcmc.HMC([p], lr=0.01, num_data=10, raise_on_nan=False, seed=3)
+        m0 = torch.randn(w.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+        opt.sample_momentum()
+        opt.state[p]['momentum_buffer'].copy_(m0)       # logical values, whatever the layout
+        gr = torch.randn(w.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+        p.grad = gr.contiguous(memory_format=torch.channels_last) if p is p_cl else gr
+        opt.initial_step(save_state=True)
+        assert opt.state[p]['momentum_buffer'].stride() == p.stride()
+        outs.append((p.detach().clone().contiguous(), opt.state[p]['momentum_buffer'].clone().contiguous(),
+                     opt.state[p]['square_avg'].clone().contiguous(), opt.delta_energy(0., 0.)))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)            # HMC draws no noise: layouts must agree bit for bit
+    assert outs[0][3] == pytest.approx(outs[1][3], rel=1e-12)
