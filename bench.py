@@ -53,6 +53,7 @@ def parse():
                     help="MIOpen find mode, as the reference sets it (experiments/train_bnn.py:29-31)")
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--samples", type=int, default=3, help="also time K full sample cycles (0 = skip)")
+    ap.add_argument("--metrics-skip", type=int, default=10, help="BASELINE configs use 10")
     ap.add_argument("--inference", default="VerletSGLDReject",
                     choices=["VerletSGLDReject", "HMCReject", "SGLDReject"],
                     help="runner, as experiments/train_bnn.py:223-234 names them (headline: VerletSGLDReject)")
@@ -164,7 +165,7 @@ def main():
     runner = runner_class(args.inference)(
         model=model, dataloader=loader, dataloader_test=empty_test, epochs_per_cycle=50,
         warmup_epochs=50 if hmc else 45, sample_epochs=0 if hmc else 5, learning_rate=0.01 if not hmc else 1e-4,
-        skip=1, metrics_skip=10, temperature=1.0, momentum=1.0 if hmc else 0.994,
+        skip=1, metrics_skip=args.metrics_skip, temperature=1.0, momentum=1.0 if hmc else 0.994,
         sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
         model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank)
     # the exact initial gradient over the synthetic pool stands in for the full-data pass
@@ -183,6 +184,7 @@ def main():
             step += 1
             x, y = batches[step % len(batches)]
             runner.leapfrog(step, x, y, last_of_epoch=False)
+        runner._drain_rows()          # every metric row of these steps has been logged
         return step
 
     step = run(args.warmup, step)
@@ -250,7 +252,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name} {args.inference} batch=128 N={N} (L={L} steps/epoch) "
-                               f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip=10 prior={prior}",
+                               f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip={args.metrics_skip} prior={prior}",
                    "params": n_params, "tensors": len(list(model.parameters())),
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
                    "step_path": path},

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from . import _hip
+from .graphed import PendingRow, _ReportSlots
 from .models.base import ClassificationModel
 
 
@@ -61,7 +62,7 @@ def _dense_layers(model):
     return lin
 
 
-class FusedDenseLeapfrog:
+class FusedDenseLeapfrog(_ReportSlots):
     @staticmethod
     def supported(potential, optimizer):
         lin = _dense_layers(potential.model)
@@ -98,7 +99,7 @@ class FusedDenseLeapfrog:
         self.nbytes_args = ctypes.sizeof(_hip.StepArgs)
         self._ring, self._k, self._pp = ring, 0, 0
         self._by_batch = {}
-        self._host_report = torch.empty(eng.report.shape, dtype=torch.float64).pin_memory()
+        self._init_slots(eng.report.numel())
 
     # ------------------------------------------------------------------ per batch size
     def _setup(self, batch):
@@ -222,7 +223,7 @@ class FusedDenseLeapfrog:
         return loss, log_prior, loss - log_prior / self.pot.N
 
     # ------------------------------------------------------------------ replay
-    def replay(self, idx, metrics=False, idx_ptr=None):
+    def replay(self, idx, metrics=False, idx_ptr=None, wait=True):
         """One leapfrog step on the rows ``idx`` (host int64 array).  Returns None, or on a
         metric step dict(loss, acc, log_prior, energy, nonfinite) after one read-back."""
         batch = len(idx)
@@ -264,11 +265,20 @@ class FusedDenseLeapfrog:
         if not metrics:
             return None
         eng.metrics_ready = True
-        self._host_report.copy_(eng.report, non_blocking=True)
-        torch.cuda.current_stream(eng.device).synchronize()
-        v = self._host_report.numpy()
-        eng._state_host = v[8:].reshape(eng.n_seg, -1).copy()
-        if v[1] != 0.0:
+        buf, ev = self._take_slot()
+        buf.copy_(eng.report, non_blocking=True)
+        ev.record()
+        n_seg = eng.n_seg
+
+        def parse(v):
+            r = dict(loss=float(v[4]), acc=float(v[5]), nonfinite=bool(v[1] != 0.0),
+                     log_prior=float(v[2]), energy=float(v[3]))
+            return r, v[8:].reshape(n_seg, -1).copy()
+        row = PendingRow(self, buf, ev, parse)
+        if not wait:
+            return row
+        r, state = row.get()
+        eng._state_host = state
+        if r["nonfinite"]:
             eng.scalars[1].zero_()
-        return dict(loss=float(v[4]), acc=float(v[5]), nonfinite=bool(v[1] != 0.0),
-                    log_prior=float(v[2]), energy=float(v[3]))
+        return r

@@ -29,7 +29,39 @@ import torch.nn.functional as F
 from . import _hip
 
 
-class GraphedLeapfrog:
+class PendingRow:
+    """A metric step's read-back in flight: one async copy of ``report`` (+ optional head
+    scalars) into a pinned slot, guarded by an event.  ``get()`` waits for it and returns
+    (dict(loss, acc, log_prior, energy, nonfinite), per-segment state array)."""
+    __slots__ = ("owner", "buf", "event", "parse")
+
+    def __init__(self, owner, buf, event, parse):
+        self.owner, self.buf, self.event, self.parse = owner, buf, event, parse
+
+    def ready(self):
+        return self.event.query()
+
+    def get(self):
+        self.event.synchronize()
+        out = self.parse(self.buf.numpy())
+        self.owner._free_slots.append((self.buf, self.event))
+        return out
+
+
+class _ReportSlots:
+    "pool of pinned read-back buffers shared by the graphed step objects"
+
+    def _init_slots(self, numel):
+        self._slot_numel = numel
+        self._free_slots = []
+
+    def _take_slot(self):
+        if self._free_slots:
+            return self._free_slots.pop()
+        return torch.empty(self._slot_numel, dtype=torch.float64).pin_memory(), torch.cuda.Event()
+
+
+class GraphedLeapfrog(_ReportSlots):
     def __init__(self, potential, optimizer, x_example, y_example, ring=8, warmup=2):
         if not potential.fast or potential.leftover:
             raise ValueError("graph capture needs the fused-prior / cross-entropy potential")
@@ -126,7 +158,7 @@ class GraphedLeapfrog:
                 self.outputs[metrics] = self._body(True, metrics)
             self.graphs[metrics] = g
             self.static_grads[metrics] = [p.grad for p in self.eng.params]
-        self._host_packed = torch.empty(self.outputs[True][1].shape, dtype=torch.float64).pin_memory()
+        self._init_slots(self.outputs[True][1].numel())
         self._bound = None
         torch.cuda.synchronize(dev)
 
@@ -134,7 +166,7 @@ class GraphedLeapfrog:
     def matches(self, x, y):
         return (tuple(x.shape), tuple(y.shape)) == self.shape
 
-    def replay(self, x, y, metrics=False):
+    def replay(self, x, y, metrics=False, wait=True):
         """One leapfrog step.  ``metrics=False``: nothing is read back, returns None.
         ``metrics=True``: the transition also updates the temperature estimates and the fused
         log-prior; returns dict(loss, acc, log_prior, energy, nonfinite) of Python floats after ONE
@@ -157,11 +189,20 @@ class GraphedLeapfrog:
         if not metrics:
             return None
         eng.metrics_ready = True
-        self._host_packed.copy_(self.outputs[True][1], non_blocking=True)
-        torch.cuda.current_stream(eng.device).synchronize()
-        v = self._host_packed.numpy()
-        eng._state_host = v[self.N_HEAD:].reshape(eng.n_seg, -1).copy()
-        if v[3] != 0.0:
+        buf, ev = self._take_slot()
+        buf.copy_(self.outputs[True][1], non_blocking=True)
+        ev.record()
+        n_head, n_seg = self.N_HEAD, eng.n_seg
+
+        def parse(v):
+            r = dict(loss=float(v[0]), acc=float(v[1]), nonfinite=bool(v[3] != 0.0),
+                     log_prior=float(v[4]), energy=float(v[5]))
+            return r, v[n_head:].reshape(n_seg, -1).copy()
+        row = PendingRow(self, buf, ev, parse)
+        if not wait:
+            return row
+        r, state = row.get()
+        eng._state_host = state
+        if r["nonfinite"]:
             eng.scalars[1].zero_()
-        return dict(loss=float(v[0]), acc=float(v[1]), nonfinite=bool(v[3] != 0.0),
-                    log_prior=float(v[4]), energy=float(v[5]))
+        return r

@@ -163,6 +163,7 @@ class SGLDRunner:
         self.use_graph = use_graph
         self._graphed = None
         self._fused = None
+        self._rows, self._draining = [], False    # metric rows whose read-back is in flight
 
     # ------------------------------------------------------------------ factories
     def _sampler_kwargs(self):
@@ -238,24 +239,54 @@ class SGLDRunner:
     def _tensors_of(x, y):
         return x.materialize() if y is None else (x, y)
 
-    def _fast_plain_step(self, x, y, store):
+    def _fast_plain_step(self, x, y, store, log_row=None):
         """Gradient + ordinary sampler ``step`` through the fastest available path.  Returns
-        (handled, r, x, y): ``handled`` False means the caller runs the eager path on the returned
-        tensors; on metric steps ``r`` = dict(loss, acc, log_prior, potential, energy) of floats."""
+        (handled, x, y): ``handled`` False means the caller runs the eager path on the returned
+        tensors.  On metric steps ``log_row(r)`` is called with r = dict(loss, acc, log_prior,
+        potential, energy) -- LATER: the read-back is asynchronous (one copy into a pinned slot,
+        guarded by an event) so that logging never stalls the launch pipeline; rows are drained
+        in order before anything else logs, evaluates or changes the sampler state."""
         by_index = y is None          # an IndexBatch from _BatchSource.index_batches()
         if by_index and self._fused_dense() is None:
             x, y = x.materialize()
             by_index = False
         graphed = self._fused_dense() if by_index else self._graph_for(x, y)
         if graphed is None:
-            return False, None, x, y
-        r = (graphed.replay(x.idx, metrics=store, idx_ptr=x.ptr) if by_index
-             else graphed.replay(x, y, metrics=store))
-        if store:
-            if r["nonfinite"]:
-                raise ValueError("Potential is NaN")
-            r["potential"] = r["loss"] - r["log_prior"] / self.eff_num_data
-        return True, r, x, y
+            return False, x, y
+        if not store:
+            if by_index:
+                graphed.replay(x.idx, idx_ptr=x.ptr)
+            else:
+                graphed.replay(x, y)
+            return True, x, y
+        row = (graphed.replay(x.idx, metrics=True, idx_ptr=x.ptr, wait=False) if by_index
+               else graphed.replay(x, y, metrics=True, wait=False))
+        self._drain_rows(block=False)
+        self._rows.append((row, log_row))
+        return True, x, y
+
+    def _drain_rows(self, block=True):
+        "log the metric rows whose read-back has landed (all of them if ``block``), oldest first"
+        rows = self._rows
+        if not rows or self._draining:
+            return
+        self._draining = True
+        try:
+            eng = self.optimizer.engine
+            while rows and (block or rows[0][0].ready()):
+                row, log_row = rows.pop(0)
+                r, state = row.get()
+                if r["nonfinite"]:
+                    eng.scalars[1].zero_()
+                    raise ValueError("Potential is NaN")
+                r["potential"] = r["loss"] - r["log_prior"] / self.eff_num_data
+                eng._state_host = state          # what store_metrics reads the per-tensor values from
+                try:
+                    log_row(r)
+                finally:
+                    eng._state_host = None
+        finally:
+            self._draining = False
 
     # ------------------------------------------------------------------ the run
     def run(self, progressbar=False):
@@ -284,9 +315,11 @@ class SGLDRunner:
                     self._save_sample(state_dict, cycle, epoch, step)
                 self._evaluate_model(state_dict, step)
                 self.metrics_saver.flush(every_s=10)
+        self._drain_rows()
         # metrics for the last sample (inference.py:182-187)
         x, y = next(iter(self._batches()))
         self.step(step + 1, x, y, store_metrics=True, initial_step=self._is_sampling_epoch(-1))
+        self._drain_rows()
 
     def _save_sample(self, state_dict, cycle, epoch, step):
         k = epoch - (self.descent_epochs + self.warmup_epochs)
@@ -299,6 +332,7 @@ class SGLDRunner:
             self.model_saver.flush()
 
     def _evaluate_model(self, state_dict, step):
+        self._drain_rows()
         if len(self.dataloader_test) == 0:
             return {}
         self.model.eval()
@@ -312,6 +346,7 @@ class SGLDRunner:
         return res
 
     def _check_finite(self):
+        self._drain_rows()
         if self.optimizer.engine.nonfinite_seen():
             raise ValueError("Potential is NaN")
 
@@ -333,16 +368,17 @@ class SGLDRunner:
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
         "inference.py:225-249"
-        handled, r, x, y = self._fast_plain_step(x, y, store_metrics)
+        lr = self.optimizer.param_groups[0]["lr"]
+
+        def log_row(r, i=i, lr=lr, initial_step=initial_step):
+            self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],   # quirk 6
+                               potential=r["potential"], acc=r["acc"], lr=lr,
+                               corresponds_to_sample=initial_step)
+        handled, x, y = self._fast_plain_step(x, y, store_metrics, log_row)
         if handled:
-            lr = self.optimizer.param_groups[0]["lr"]
             if lr_decay:
                 self.scheduler.step()
-            if store_metrics:
-                self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],   # quirk 6
-                                   potential=r["potential"], acc=r["acc"], lr=lr,
-                                   corresponds_to_sample=initial_step)
-            return r and r["loss"], r and r["acc"], None
+            return None, None, None
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store_metrics)
         self.optimizer.step(calc_metrics=store_metrics)
         lr = self.optimizer.param_groups[0]["lr"]
@@ -363,6 +399,7 @@ class SGLDRunner:
     def store_metrics(self, i, loss, log_prior, potential, acc, lr, corresponds_to_sample,
                       delta_energy=None, total_energy=None, rejected=None):
         "inference.py:262-294; one D2H copy serves every per-tensor scalar below"
+        self._drain_rows()      # earlier rows first (no-op while a row is being logged)
         add = self.metrics_saver.add_scalar
         t_all = c_all = 0.
         numel = 0
@@ -400,22 +437,19 @@ class VerletSGLDRunner(SGLDRunner):
 
     def step(self, i, x, y, store_metrics, lr_decay=True, initial_step=False):
         if i != 0 and not initial_step:
-            handled, r, x, y = self._fast_plain_step(x, y, store_metrics)
+            lr0 = self.optimizer.param_groups[0]["lr"]
+
+            def log_row(r, i=i, lr=lr0, u0=self._initial_potential, e0=self._total_energy):
+                # quirk 13: the reference passes `loss` where a potential is expected
+                de = self.optimizer.delta_energy_from_total(r["energy"], u0, r["loss"])
+                self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],
+                                   potential=r["potential"], acc=r["acc"], lr=lr, delta_energy=de,
+                                   total_energy=e0 + de, rejected=None, corresponds_to_sample=False)
+            handled, x, y = self._fast_plain_step(x, y, store_metrics, log_row)
             if handled:
-                lr = self.optimizer.param_groups[0]["lr"]
-                delta_energy = None
-                if store_metrics:
-                    # quirk 13: the reference passes `loss` where a potential is expected
-                    delta_energy = self.optimizer.delta_energy_from_total(
-                        r["energy"], self._initial_potential, r["loss"])
-                    self.store_metrics(i=i - 1, loss=r["loss"], log_prior=r["log_prior"],
-                                       potential=r["potential"], acc=r["acc"], lr=lr,
-                                       delta_energy=delta_energy,
-                                       total_energy=self._total_energy + delta_energy,
-                                       rejected=None, corresponds_to_sample=initial_step)
                 if lr_decay:
                     self.scheduler.step()
-                return r and r["loss"], r and r["acc"], delta_energy
+                return None, None, None
         x, y = self._tensors_of(x, y)
         # an M-H point or the very first step always stores metrics (see below)
         want = store_metrics or i == 0 or initial_step

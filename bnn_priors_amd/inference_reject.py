@@ -45,23 +45,18 @@ class VerletSGLDRunnerReject(SGLDRunner):
         metrics every ``metrics_skip`` steps, LR schedule (inference_reject.py:86-113)."""
         store = (step % self.metrics_skip) == 0
         opt = self.optimizer
-        handled, r, x, y = self._fast_plain_step(x, y, store)
+        def log_row(r, step=step, lr=opt.param_groups[0]["lr"], u0=self._initial_potential,
+                    e0=self._total_energy):
+            de = opt.delta_energy_from_total(r["energy"], u0, r["potential"])
+            self.store_metrics(i=step, loss=r["loss"], log_prior=r["log_prior"],
+                               potential=r["potential"], acc=r["acc"], lr=lr,
+                               corresponds_to_sample=False, delta_energy=de, total_energy=e0 + de)
+        handled, x, y = self._fast_plain_step(x, y, store, log_row)
         if handled:
-            acc = None
-            if store:
-                delta_energy = opt.delta_energy_from_total(r["energy"], self._initial_potential,
-                                                           r["potential"])
-                self.store_metrics(i=step, loss=r["loss"], log_prior=r["log_prior"],
-                                   potential=r["potential"], acc=r["acc"],
-                                   lr=opt.param_groups[0]["lr"], corresponds_to_sample=False,
-                                   delta_energy=delta_energy,
-                                   total_energy=self._total_energy + delta_energy)
-                acc = r["acc"]
             if not last_of_epoch:
                 self.scheduler.step()
-            elif acc is None:                                # quirk 5: the sample row logs it
-                acc = self._potential().accuracy(*self._tensors_of(x, y))
-            return acc
+                return None
+            return self._potential().accuracy(*self._tensors_of(x, y))   # quirk 5: the sample row logs it
         loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
         opt.step(calc_metrics=store)
         if store:
@@ -133,6 +128,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                         step += 1
                         acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
 
+                    self._drain_rows()
                     if self._is_sampling_epoch(epoch):
                         step += 1                                                    # quirk 6
                         loss, log_prior, potential = self._exact_model_potential_and_grad(batches)
