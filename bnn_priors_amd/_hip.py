@@ -88,7 +88,7 @@ class MlpArgs(ctypes.Structure):
                 ("out_features", ctypes.c_int32), ("inv_softmax_temp", ctypes.c_float),
                 ("trace", ctypes.c_void_p), ("args_src", ctypes.c_void_p),
                 ("args_dst", ctypes.c_void_p), ("args_bytes", ctypes.c_int32),
-                ("grad_scale", ctypes.c_float)]
+                ("grad_scale", ctypes.c_float), ("split_scratch", ctypes.c_void_p)]
 
 
 EXPORTS = {
@@ -120,6 +120,7 @@ EXPORTS = {
                                          ctypes.c_uint32, ctypes.c_void_p]),
     "sgmcmc_mlp_fwdbwd": (ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.c_void_p]),
     "sgmcmc_mlp_lds_bytes": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_mlp_split_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
     "sgmcmc_grad_reduce_prior": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_void_p, ctypes.c_int,
                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_int, ctypes.c_double, ctypes.c_uint32,

@@ -83,6 +83,8 @@ class FusedDenseLeapfrog(_ReportSlots):
         import os
         # three direct launches with by-value arguments vs replaying a captured graph
         self.direct = (os.environ.get("SGMCMC_DENSE_DIRECT", "1") == "1") if direct is None else direct
+        # forward/backward as two launches over 4x more workgroups (csrc/mlp_hip.inc, 'two-launch split')
+        self.split = os.environ.get("SGMCMC_DENSE_SPLIT", "1") == "1"
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.lib = _hip.lib()
         eng, dev = self.eng, optimizer.engine.device
@@ -112,6 +114,7 @@ class FusedDenseLeapfrog(_ReportSlots):
         st["gpart"] = torch.zeros(S * self.stride, device=dev)
         st["loss_part"] = torch.zeros(S, device=dev)
         st["corr_part"] = torch.zeros(S, device=dev)
+        st["split"] = torch.zeros(self.lib.sgmcmc_mlp_split_scratch_floats(batch), device=dev)
         W1, b1, W2, b2, W3, b3 = eng.params
         o = self.offs
         st["mlp"] = _hip.MlpArgs(
@@ -123,7 +126,8 @@ class FusedDenseLeapfrog(_ReportSlots):
             off_W3=o[4], off_b3=o[5], batch=batch, in_features=W1.shape[1], hidden1=W1.shape[0],
             hidden2=W2.shape[0], out_features=W3.shape[0],
             inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None,
-            args_src=None, args_dst=None, args_bytes=0, grad_scale=0.0)
+            args_src=None, args_dst=None, args_bytes=0, grad_scale=0.0,
+            split_scratch=st["split"].data_ptr() if self.split else None)
         st["param_ptrs"] = [p.data_ptr() for p in eng.params]
         self._bind_grads()
         eng.refresh(self.opt._preconditioners())
@@ -204,7 +208,8 @@ class FusedDenseLeapfrog(_ReportSlots):
                 off_W3=o[4], off_b3=o[5], batch=mb, in_features=in_f, hidden1=W1.shape[0],
                 hidden2=W2.shape[0], out_features=W3.shape[0],
                 inv_softmax_temp=1.0 / float(self.pot.model.softmax_temp), trace=None,
-                args_src=None, args_dst=None, args_bytes=0, grad_scale=1.0 / self.pot.N)
+                args_src=None, args_dst=None, args_bytes=0, grad_scale=1.0 / self.pot.N,
+                split_scratch=None)
             _hip.check(lib.sgmcmc_mlp_fwdbwd(ctypes.byref(A), stream), "sgmcmc_mlp_fwdbwd")
             last = start + mb >= n_data
             _hip.check(lib.sgmcmc_accumulate_parts(

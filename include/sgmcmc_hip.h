@@ -243,7 +243,13 @@ typedef struct {
   /* > 0: dL/dlogits is scaled by this instead of 1/batch.  The exact full-data gradient
    * (inference_reject.py:18-33) is the sum over mega-batches of  -sum_i log p_i / N : scale = 1/N */
   float grad_scale;
+  /* optional (else NULL): sgmcmc_mlp_split_scratch_floats(batch) floats of device scratch.  When
+   * given, sgmcmc_dense_step_direct runs the forward/backward as TWO launches that spread the two
+   * 784-wide contractions over 4x more workgroups (lower latency; same partial-gradient layout). */
+  float* split_scratch;
 } sgmcmc_mlp_args;
+
+int64_t sgmcmc_mlp_split_scratch_floats(int batch);
 
 int sgmcmc_mlp_fwdbwd(const sgmcmc_mlp_args* P, void* stream);
 int64_t sgmcmc_mlp_lds_bytes(int in_features);
