@@ -279,7 +279,8 @@ struct PriorCoef {
   T locT, c_normal, c_laplace, c_t_num, c_t_den;
   __device__ __forceinline__ void init(const sgmcmc_segment* sp, double num_data) {
     kind = sp->prior_kind;
-    loc = sp->prior_loc; scale = sp->prior_scale; df = sp->prior_df;
+    loc = sp->prior_loc; scale = sp->prior_scale;
+    df = kind == SGMCMC_PRIOR_CAUCHY ? 1.0 : sp->prior_df;
     locT = (T)loc;
     c_normal = (T)(1.0 / (scale * scale * num_data));
     c_laplace = (T)(1.0 / (scale * num_data));
@@ -294,7 +295,7 @@ struct PriorCoef {
     } else if (kind == SGMCMC_PRIOR_LAPLACE) {
       const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
       g = fma_t<T>(sgn, c_laplace, g);
-    } else {
+    } else {  // Student-t (df) and Cauchy (= Student-t with df = 1, set by PriorCoef::init)
       g = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g);
     }
     if (calc_logp) {
@@ -744,6 +745,7 @@ __device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s) {
   if (s.prior_kind == SGMCMC_PRIOR_STUDENT_T)
     return -log(s.prior_scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
            lgamma(0.5 * s.prior_df) + lgamma(0.5 * (s.prior_df + 1.0));
+  if (s.prior_kind == SGMCMC_PRIOR_CAUCHY) return -log(s.prior_scale) - 1.1447298858494001741;  // -ln(pi sigma)
   return 0.0;
 }
 

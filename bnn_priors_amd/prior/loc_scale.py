@@ -10,9 +10,9 @@ import torch.distributions as td
 from .base import Prior
 
 __all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "Improper", "get_prior",
-           "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T")
+           "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T", "FUSED_CAUCHY")
 
-FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T = 0, 1, 2, 3
+FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T, FUSED_CAUCHY = 0, 1, 2, 3, 4
 
 
 class LocScale(Prior):
@@ -32,6 +32,7 @@ class Laplace(LocScale):
 
 class Cauchy(LocScale):
     _dist = td.Cauchy
+    fused_kind = FUSED_CAUCHY
 
 
 class StudentT(LocScale):
@@ -44,7 +45,7 @@ class StudentT(LocScale):
 
 class Improper(Normal):
     "samples like a Normal, contributes nothing to the log-density"
-    fused_kind = None
+    fused_kind = FUSED_NONE      # "fused" as a no-op: neither gradient nor log-density
 
     def log_prob(self):
         return 0.0

@@ -63,7 +63,7 @@ enum {
 };
 /* element-wise priors the step kernel can differentiate in-flight (prior/loc_scale.py) */
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
-       SGMCMC_PRIOR_STUDENT_T = 3 };
+       SGMCMC_PRIOR_STUDENT_T = 3, SGMCMC_PRIOR_CAUCHY = 4 };
 
 /* One parameter tensor.  Device-resident array, written by the host. */
 typedef struct {

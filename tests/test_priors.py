@@ -15,7 +15,8 @@ def test_closed_forms_cpu():
     th = torch.randn(1000, dtype=torch.float64) * 3
     for cls, dist, kw in ((P.Normal, torch.distributions.Normal, {}),
                           (P.Laplace, torch.distributions.Laplace, {}),
-                          (P.StudentT, torch.distributions.StudentT, {"df": 3})):
+                          (P.StudentT, torch.distributions.StudentT, {"df": 3}),
+                          (P.Cauchy, torch.distributions.Cauchy, {})):
         loc, scale = 0.3, 1.7
         t = th.clone().requires_grad_(True)
         args = ((kw["df"], loc, scale) if kw else (loc, scale))
@@ -26,6 +27,8 @@ def test_closed_forms_cpu():
             g = -d / scale ** 2
         elif cls is P.Laplace:
             g = -torch.sign(d) / scale
+        elif cls is P.Cauchy:
+            g = -2 * d / (scale ** 2 + d ** 2)
         else:
             g = -(3 + 1) * d / (3 * scale ** 2 + d ** 2)
         assert torch.allclose(t.grad, g, rtol=1e-12, atol=1e-14)
@@ -41,7 +44,7 @@ def test_fused_prior_kernel_matches_autograd(dtype):
     try:
         torch.manual_seed(1)
         priors = [P.Normal((5000,), 0.1, 0.7), P.Laplace((4097,), -0.2, 1.3),
-                  P.StudentT((33, 5), 0.0, 0.4, df=3), P.Normal((3,), 0., 2.),
+                  P.StudentT((33, 5), 0.0, 0.4, df=3), P.Cauchy((1025,), 0.3, 0.9),
                   P.Normal((7,), 0., torch.linspace(0.5, 1.5, 7))]     # last one: not fusable
         model = torch.nn.ModuleList(priors).to(dev)
         free = torch.nn.Parameter(torch.randn(10, device=dev))          # parameter without a prior

@@ -54,6 +54,13 @@ def _check(name, metrics, runner, rtol, atol, de_atol, acc_atol=0.0):
     first = next(iter(k for k in samples if k.endswith("0.weight_prior.p")))
     np.testing.assert_allclose(samples[first][:, :2, :8].cpu().numpy(), g[f"{name}/sample_first_weight"],
                                rtol=rtol * 10, atol=atol)
+    # posterior-predictive ensemble of the stored samples vs the reference's evaluate_model
+    from bnn_priors_amd.evaluation import evaluate_model
+    dev = runner._device
+    ev = evaluate_model(runner.model, runner.dataloader_test, {k: v.to(dev) for k, v in samples.items()})
+    got = np.array([ev["lp_ensemble"], ev["lp_last"], ev["acc_ensemble"], ev["acc_last"]])
+    np.testing.assert_allclose(got, g[f"{name}/evaluate_model"], rtol=max(rtol, 1e-5),
+                               atol=max(atol, acc_atol), err_msg=f"{name}:evaluate_model")
 
 
 # ------------------------------------------------------------------ CPU: host logic
