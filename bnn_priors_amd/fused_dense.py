@@ -228,7 +228,7 @@ class FusedDenseLeapfrog(_ReportSlots):
         return loss, log_prior, loss - log_prior / self.pot.N
 
     # ------------------------------------------------------------------ replay
-    def replay(self, idx, metrics=False, idx_ptr=None, wait=True):
+    def replay(self, idx, metrics=False, idx_ptr=None, wait=True, calc_metrics=None):
         """One leapfrog step on the rows ``idx`` (host int64 array).  Returns None, or on a
         metric step dict(loss, acc, log_prior, energy, nonfinite) after one read-back."""
         batch = len(idx)
@@ -251,7 +251,7 @@ class FusedDenseLeapfrog(_ReportSlots):
         if self.direct and batch <= 256:
             # ping-pong argument structs: the previous step's may still be pending
             self._pp ^= 1
-            A = self._args(st["App"][self._pp], metrics)
+            A = self._args(st["App"][self._pp], metrics if calc_metrics is None else calc_metrics)
             if not metrics and eng.small_finalize:
                 A.flags |= _hip.DEFER_FINALIZE      # its bookkeeping rides in the NEXT launch
             pending, eng.pending = eng.pending, None
@@ -261,7 +261,7 @@ class FusedDenseLeapfrog(_ReportSlots):
                 eng.pending = A
         else:
             eng.flush()
-            A = self._args(st["A"], metrics)
+            A = self._args(st["A"], metrics if calc_metrics is None else calc_metrics)
             err = self.lib.sgmcmc_dense_stepper_step(st["handle"], A, idx_ptr, eng.stream())
         if err:
             _hip.check(err, "sgmcmc_dense_step")

@@ -166,7 +166,7 @@ class GraphedLeapfrog(_ReportSlots):
     def matches(self, x, y):
         return (tuple(x.shape), tuple(y.shape)) == self.shape
 
-    def replay(self, x, y, metrics=False, wait=True):
+    def replay(self, x, y, metrics=False, wait=True, calc_metrics=None):
         """One leapfrog step.  ``metrics=False``: nothing is read back, returns None.
         ``metrics=True``: the transition also updates the temperature estimates and the fused
         log-prior; returns dict(loss, acc, log_prior, energy, nonfinite) of Python floats after ONE
@@ -182,7 +182,9 @@ class GraphedLeapfrog(_ReportSlots):
             for p, g in zip(eng.params, self.static_grads[metrics]):
                 p.grad = g
         eng.refresh(self.opt._preconditioners())
-        self._push_args(self._args(calc_metrics=metrics))
+        # ``metrics`` picks the graph variant (with accuracy / log-prior / packed read-back);
+        # ``calc_metrics`` (default: the same) is the sampler's own flag, read from the args at run time
+        self._push_args(self._args(calc_metrics=metrics if calc_metrics is None else calc_metrics))
         self.graphs[metrics].replay()
         eng._touch()
         eng.energy_ready = True

@@ -73,18 +73,28 @@ class _BatchSource:
         return len(self.dl)
 
     def _permutation(self):
+        """(permutation, generator) exactly as torch/utils/data/sampler.py RandomSampler.__iter__
+        draws them; ``_exhausted`` below replays what it does when the iteration runs out."""
         s, n = self.dl.sampler, len(self.dl.dataset)
         if isinstance(s, torch.utils.data.SequentialSampler):
-            return None
+            return None, None
         if s.replacement or s._num_samples is not None:
-            return torch.tensor(list(iter(s)), dtype=torch.int64)
-        if s.generator is None:   # torch/utils/data/sampler.py: RandomSampler.__iter__
+            return torch.tensor(list(iter(s)), dtype=torch.int64), None
+        if s.generator is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             gen = torch.Generator()
             gen.manual_seed(seed)
         else:
             gen = s.generator
-        return torch.randperm(n, generator=gen)
+        return torch.randperm(n, generator=gen), gen
+
+    def _exhausted(self, gen):
+        """RandomSampler ends with ``randperm(n)[: num_samples % n]`` -- an empty slice of a SECOND
+        permutation, drawn when the iteration is exhausted.  With a generator shared across passes
+        (the reject runner's per-cycle generator) that draw decides the batch composition of the
+        next pass, which BatchNorm nets feel; reproduce it."""
+        if gen is not None:
+            torch.randperm(len(self.dl.dataset), generator=gen)
 
     def __iter__(self):
         return self._iterate(False)
@@ -104,13 +114,14 @@ class _BatchSource:
         # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__): keep the global
         # RNG stream aligned with a run that iterates the DataLoader itself
         torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
-        perm = self._permutation()
+        perm, gen = self._permutation()
         stop = n - n % bs if self.dl.drop_last else n
         if by_index:
             from .fused_dense import IndexBatch
             host = (perm if perm is not None else torch.arange(n)).numpy()
             for i in range(0, stop, bs):
                 yield IndexBatch(host[i:i + bs], self.x, self.y), None
+            self._exhausted(gen)
             return
         if perm is not None:
             perm = perm.to(self.device)
@@ -120,6 +131,7 @@ class _BatchSource:
             else:
                 idx = perm[i:i + bs]
                 yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+        self._exhausted(gen)
 
 
 class SGLDRunner:
@@ -239,7 +251,7 @@ class SGLDRunner:
     def _tensors_of(x, y):
         return x.materialize() if y is None else (x, y)
 
-    def _fast_plain_step(self, x, y, store, log_row=None):
+    def _fast_plain_step(self, x, y, store, log_row=None, want_acc=False):
         """Gradient + ordinary sampler ``step`` through the fastest available path.  Returns
         (handled, x, y): ``handled`` False means the caller runs the eager path on the returned
         tensors.  On metric steps ``log_row(r)`` is called with r = dict(loss, acc, log_prior,
@@ -254,7 +266,15 @@ class SGLDRunner:
         if graphed is None:
             return False, x, y
         if not store:
-            if by_index:
+            if want_acc:
+                # the minibatch accuracy of THIS forward pass (no second forward: BatchNorm buffers
+                # must see each batch once): metrics-variant replay, sampler metrics off
+                r = (graphed.replay(x.idx, metrics=True, idx_ptr=x.ptr, calc_metrics=False) if by_index
+                     else graphed.replay(x, y, metrics=True, calc_metrics=False))
+                self.optimizer.engine._state_host = None
+                self._drain_rows()            # older metric rows log (and set _last_acc) first
+                self._last_acc = r["acc"]
+            elif by_index:
                 graphed.replay(x.idx, idx_ptr=x.ptr)
             else:
                 graphed.replay(x, y)

@@ -48,16 +48,19 @@ class VerletSGLDRunnerReject(SGLDRunner):
         def log_row(r, step=step, lr=opt.param_groups[0]["lr"], u0=self._initial_potential,
                     e0=self._total_energy):
             de = opt.delta_energy_from_total(r["energy"], u0, r["potential"])
+            self._last_acc = r["acc"]
             self.store_metrics(i=step, loss=r["loss"], log_prior=r["log_prior"],
                                potential=r["potential"], acc=r["acc"], lr=lr,
                                corresponds_to_sample=False, delta_energy=de, total_energy=e0 + de)
-        handled, x, y = self._fast_plain_step(x, y, store, log_row)
+        # quirk 5: the sample row logs the LAST minibatch's accuracy, so that one is always wanted
+        handled, x, y = self._fast_plain_step(x, y, store, log_row, want_acc=last_of_epoch)
         if handled:
             if not last_of_epoch:
                 self.scheduler.step()
                 return None
-            return self._potential().accuracy(*self._tensors_of(x, y))   # quirk 5: the sample row logs it
-        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store)
+            self._drain_rows()
+            return self._last_acc
+        loss, log_prior, potential, acc = self._model_potential_and_grad(x, y, store or last_of_epoch)
         opt.step(calc_metrics=store)
         if store:
             self._check_finite()
@@ -69,8 +72,6 @@ class VerletSGLDRunnerReject(SGLDRunner):
                                total_energy=self._total_energy + _f(delta_energy))
         if not last_of_epoch:   # the last scheduler step of an epoch follows final_step
             self.scheduler.step()
-        elif acc is None:       # the sample row logs the last minibatch's accuracy (quirk 5)
-            acc = self._potential().accuracy(x, y) if self._potential().fast else acc
         return acc
 
     def _delta_energy(self, potential):

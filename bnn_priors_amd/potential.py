@@ -65,10 +65,6 @@ class Potential:
             acc = f.argmax(dim=1).eq(y).float().mean()
         return loss.detach(), log_prior, potential, acc
 
-    def accuracy(self, x, y):
-        with torch.no_grad():
-            return self._logits(x).argmax(dim=1).eq(y).float().mean()
-
     # ------------------------------------------------------------------ full-data gradient
     def exact(self, batches):
         """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N]
