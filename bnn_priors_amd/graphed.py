@@ -208,3 +208,70 @@ class GraphedLeapfrog(_ReportSlots):
         if r["nonfinite"]:
             eng.scalars[1].zero_()
         return r
+
+
+class GraphedAccumulate:
+    """The body of the exact full-data gradient (reference: inference_reject.py:24-30),
+
+        g += grad[ -sum_i log p(y_i | x_i) / N ]     loss += -sum_i log p(y_i | x_i) / N
+
+    captured once on static inputs and replayed per full-size batch: autograd accumulates into
+    the SAME gradient tensors on every replay (``p.grad`` bound to ``self.grads``), the loss into a
+    float64 device scalar.  An epoch-long pass is then L graph launches and no host read-back;
+    off-shape batches (the ragged last one) run the same ops eagerly into the same accumulators.
+    BatchNorm nets update their running statistics on every replay exactly as the eager pass does;
+    the capture's warm-up runs are undone from a snapshot of the model's buffers."""
+
+    def __init__(self, potential, optimizer, x_example, y_example, warmup=2):
+        self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
+        self.model = potential.model
+        dev = self.eng.device
+        self.x = torch.empty_like(x_example, device=dev)
+        self.y = torch.empty_like(y_example, device=dev)
+        self.shape = (tuple(self.x.shape), tuple(self.y.shape))
+        self.loss = torch.zeros((), dtype=torch.float64, device=dev)
+        self.grads = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.eng.params]
+        self.x.copy_(x_example)
+        self.y.copy_(y_example)
+        buffers = {k: v.clone() for k, v in self.model.state_dict().items()}
+        self.begin()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(buffers[k])
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        this = F.cross_entropy(self.pot._logits(self.x), self.y, reduction="sum") / self.pot.N
+        this.backward()
+        self.loss += this.detach().double()
+
+    def matches(self, x, y):
+        return (tuple(x.shape), tuple(y.shape)) == self.shape
+
+    def begin(self):
+        "zero the accumulators and make them the parameters' gradients"
+        torch._foreach_zero_(self.grads)
+        self.loss.zero_()
+        for p, g in zip(self.eng.params, self.grads):
+            p.grad = g
+
+    def add(self, x, y):
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self.graph.replay()
+
+    def add_eager(self, x, y):
+        "same accumulation without the graph (any batch shape)"
+        this = F.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
+        this.backward()
+        self.loss += this.detach().double()

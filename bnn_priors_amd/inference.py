@@ -376,6 +376,7 @@ class SGLDRunner:
         except AttributeError:
             from .potential import Potential
             self._potential_obj = Potential(self.model, self.optimizer, self.eff_num_data)
+            self._potential_obj.graph_exact = bool(self.use_graph)
             return self._potential_obj
 
     def _model_potential_and_grad(self, x, y, want_metrics=True):

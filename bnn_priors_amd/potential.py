@@ -66,6 +66,12 @@ class Potential:
         return loss.detach(), log_prior, potential, acc
 
     # ------------------------------------------------------------------ full-data gradient
+    graph_exact = False     # set by the runner (``use_graph``): capture the exact pass's batch body
+
+    def _may_graph_exact(self, batches):
+        return (self.graph_exact and not self.leftover and self.opt.engine.device.type == "cuda"
+                and len(batches) >= 4)      # fewer batches are not worth a capture
+
     def exact(self, batches):
         """g <- grad[-log_prior/N] + sum_batches grad[-sum_i log p_i / N]
         (reference: inference_reject.py:18-33).  Returns (loss, log_prior, potential)."""
@@ -80,11 +86,25 @@ class Potential:
                 this.backward()
                 loss = loss + this.detach()
             return loss, log_prior.detach(), loss + lnp.detach()
+        acc = getattr(self, "_exact_acc", None)
+        may_graph = acc is not None or self._may_graph_exact(batches)
         loss = torch.zeros((), dtype=torch.float64, device=self.opt.engine.device)
-        for x, y in batches:
-            this = F.cross_entropy(self._logits(x), y, reduction="sum") / self.N
-            this.backward()
-            loss = loss + this.detach().double()
+        if acc is not None:
+            acc.begin()
+        for x, y in batches:        # (never peeked at: iterating the loader draws from its RNG)
+            if may_graph and acc is None:
+                # graph-captured accumulation (graphed.GraphedAccumulate): L launches, no read-back
+                from .graphed import GraphedAccumulate
+                acc = self._exact_acc = GraphedAccumulate(self, self.opt, x, y)
+                acc.begin()
+            if acc is not None:
+                (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
+            else:
+                this = F.cross_entropy(self._logits(x), y, reduction="sum") / self.N
+                this.backward()
+                loss = loss + this.detach().double()
+        if acc is not None:
+            loss = acc.loss.clone()
         extra = self._leftover_log_prior()
         if extra is not None:
             (extra / -self.N).backward()

@@ -1,0 +1,194 @@
+"""The HDF5 sample / metrics store against the reference's own store test
+(testing/test_exp_utils.py:27-80) and against ``h5dump``'s view of the file layout."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from bnn_priors_amd import _h5, storage
+
+pytestmark = pytest.mark.skipif(not _h5.available(), reason="libhdf5 (>= 1.10) not found on this machine")
+H5DUMP = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+
+
+def test_recorded_metrics_like_the_reference_test(tmp_path):
+    "test_exp_utils.py:27-80, with a SWMR reader opened while the writer still holds the file"
+    fname = tmp_path / "metrics_test.h5"
+    with storage.HDF5Metrics(fname, "w", chunk_size=13) as metrics:
+        for step in range(-1, 100):
+            metrics.add_scalar("re_step", step, step)
+            if step == -1 or step % 5 == 0:
+                metrics.add_scalar("step5", step // 5, step)
+            if step == -1 or step % 11 == 0:
+                metrics.add_scalar("step11", float(step // 11), step)
+            if step == -1 or step % 23 == 0:
+                metrics.add_scalar("step23", step // 23, step)
+            if step % 31 == 0:
+                metrics.flush()
+                with _h5.File(fname, "r", swmr=True) as reader:
+                    for k in reader.keys():
+                        assert len(reader[k]) == step + 2
+
+    with _h5.File(fname, "r") as f:
+        assert sorted(f.keys()) == ["re_step", "step11", "step23", "step5", "steps", "timestamps"]
+        for k in f.keys():
+            assert len(f[k]) == 101
+            if k != "timestamps":
+                assert f[k][0] == -1
+        assert np.all(~np.isnan(f["timestamps"][:]))
+        assert np.array_equal(f["steps"][:], np.arange(-1, 100))
+        assert np.array_equal(f["steps"][:], f["re_step"][:])
+        assert f["steps"].dtype == np.int64 and f["step11"].dtype == np.float64
+
+        assert np.array_equal(f["step5"][1::5], np.arange(100 // 5))
+        for i in range(1, 5):
+            assert np.all(f["step5"][1 + i::5] == -2 ** 63)
+        assert np.array_equal(f["step11"][1::11], np.arange(100 // 11 + 1).astype(np.float64))
+        for i in range(1, 11):
+            assert np.all(np.isnan(f["step11"][1 + i::11]))
+        assert np.array_equal(f["step23"][1::23], np.arange(100 // 23 + 1))
+        for i in range(1, 23):
+            assert np.all(f["step23"][1 + i::23] == -2 ** 63)
+        assert f["step5"].creation_properties() == ((13,), [3])        # filter 3 = Fletcher-32
+
+
+def test_metrics_errors_and_nested_names(tmp_path):
+    with storage.HDF5Metrics(tmp_path / "m.h5", "w", chunk_size=4) as m:
+        m.add_scalar("est_temperature/all", 1.5, 0)
+        m.add_scalar("acceptance/rejected", 0, 0)
+        m.add_scalar("est_temperature/all", 2.5, 3)
+        with pytest.raises(ValueError, match="step went backwards"):
+            m.add_scalar("est_temperature/all", 2.5, 2)
+        m.flush()
+        m.add_scalar("late_key", 1.0, 4)
+        with pytest.raises(KeyError, match="SWMR"):
+            m.flush()
+        del m._cache["late_key"]
+    with _h5.File(tmp_path / "m.h5") as f:
+        assert sorted(f.dataset_names()) == ["acceptance/rejected", "est_temperature/all", "steps", "timestamps"]
+        assert np.array_equal(f["steps"][:], [0, 3, 4])
+        assert np.array_equal(f["est_temperature/all"][:2], [1.5, 2.5]) and np.isnan(f["est_temperature/all"][2])
+        assert np.array_equal(f["acceptance/rejected"][:], [0, -2 ** 63, -2 ** 63])
+
+
+def _net():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 2))
+
+
+def test_model_saver_round_trip_and_layout(tmp_path):
+    path = tmp_path / "samples.h5"
+    net = _net()
+    want = []
+    with storage.HDF5ModelSaver(path, "w") as saver:
+        for i in range(4):
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.25 * (i + 1))
+                net[1].num_batches_tracked += 1
+            saver.add_state_dict(net.state_dict(), 10 * i + 7)
+            want.append({k: v.clone() for k, v in net.state_dict().items()})
+        mid = saver.load_samples()                      # readable while the writer is open
+        assert mid["steps"].tolist() == [7, 17, 27, 37]
+    for out in (storage.load_samples(path), mid):
+        assert set(out) == set(want[0]) | {"steps", "timestamps"}
+        for k in want[0]:
+            assert out[k].dtype == want[0][k].dtype
+            assert torch.equal(out[k], torch.stack([w[k] for w in want])), k
+    sub = storage.load_samples(path, idx=slice(1, 3), keep_steps=False)
+    assert "steps" not in sub and "timestamps" not in sub
+    assert torch.equal(sub["0.weight"], torch.stack([w["0.weight"] for w in want[1:3]]))
+    assert storage.load_samples(path, idx=-1)["steps"].item() == 37
+    with _h5.File(path) as f:
+        assert f["0.weight"].creation_properties() == ((1, 4, 3), [3])
+        assert f["1.num_batches_tracked"].shape == (4,) and f["1.num_batches_tracked"].dtype == np.int64
+    with pytest.raises(TypeError, match="NaN"):
+        with storage.HDF5ModelSaver(tmp_path / "bad.h5", "w") as saver:
+            saver.add_state_dict({"flag": torch.zeros(3, dtype=torch.bool)}, 0)
+
+
+@pytest.mark.skipif(H5DUMP is None, reason="h5dump not installed")
+def test_file_layout_as_h5dump_sees_it(tmp_path):
+    "an independent reader (the HDF5 tools) agrees on type, extent, chunking, checksum and fill value"
+    path = tmp_path / "samples.h5"
+    with storage.HDF5ModelSaver(path, "w") as saver:
+        for i in range(3):
+            saver.add_state_dict(_net().state_dict(), i)
+    out = subprocess.run([H5DUMP, "-H", "-p", "-d", "/0.weight", str(path)], capture_output=True, text=True,
+                         check=True).stdout
+    squeezed = " ".join(out.split())
+    for piece in ("DATATYPE H5T_IEEE_F32LE", "SIMPLE { ( 3, 4, 3 ) / ( H5S_UNLIMITED, 4, 3 ) }",
+                  "CHUNKED ( 1, 4, 3 )", "CHECKSUM FLETCHER32", "VALUE nan"):
+        assert piece in squeezed, (piece, out)
+    data = subprocess.run([H5DUMP, "-d", "/steps", str(path)], capture_output=True, text=True, check=True).stdout
+    assert "(0): 0, 1, 2" in data
+
+
+def test_load_samples_falls_back_to_torch_files(tmp_path):
+    path = tmp_path / "samples.pt"
+    torch.save({"w": torch.arange(6.).reshape(3, 2), "steps": torch.tensor([1, 2, 3])}, path)
+    out = storage.load_samples(path, idx=slice(0, 2))
+    assert torch.equal(out["w"], torch.arange(4.).reshape(2, 2))
+
+
+def test_reject_samples_rewinds_rejected_rows(tmp_path):
+    mpath = tmp_path / "metrics.h5"
+    with storage.HDF5Metrics(mpath, "w", chunk_size=8) as m:
+        for step, (is_sample, rejected) in enumerate([(1, 0), (0, None), (1, 1), (1, 0), (0, None), (1, 1)]):
+            m.add_scalar("acceptance/is_sample", is_sample, step)
+            if rejected is not None:
+                m.add_scalar("acceptance/rejected", rejected, step)
+    samples = {"w": torch.tensor([[0.], [2.], [3.], [5.]]), "steps": torch.tensor([0, 2, 3, 5])}
+    with _h5.File(mpath) as f:
+        storage.reject_samples_(samples, f)
+    assert samples["w"].flatten().tolist() == [0., 0., 3., 3.]
+    with storage.HDF5Metrics(tmp_path / "plain.h5", "w", chunk_size=8) as m:
+        m.add_scalar("loss", 1.0, 0)
+    with _h5.File(tmp_path / "plain.h5") as f:
+        assert storage.reject_samples_(samples, f) is samples
+
+
+@pytest.mark.gpu
+def test_runner_through_hdf5_sinks_matches_memory_sinks(tmp_path):
+    "the same run logged to HDF5 files and to the in-memory sinks: identical streams and samples"
+    from bnn_priors_amd import inference_reject, models
+    import runner_cases as RC
+
+    def run(metrics, saver):
+        cfg = RC.CASES["VerletSGLDReject"]
+        train, test, (x, y) = RC.make_data("cuda:0")
+        model = RC.make_net(models, x, y, device="cuda:0")
+        torch.manual_seed(RC.SEED)
+        runner = inference_reject.VerletSGLDRunnerReject(
+            model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+            temperature=cfg["temperature"], momentum=cfg["momentum"], reject_samples=True,
+            metrics_saver=metrics, model_saver=saver, seed=RC.SEED, chain_id=0,
+            cycle_seed=RC.CYCLE_SEED, **RC.RUN_KW)
+        runner.run()
+        return runner.get_samples()
+
+    mem = storage.MemoryMetrics()
+    want = run(mem, None)
+    with storage.HDF5Metrics(tmp_path / "metrics.h5", "w", chunk_size=4) as hm, \
+            storage.HDF5ModelSaver(tmp_path / "samples.h5", "w") as hs:
+        got = run(hm, hs)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k].to(want[k].device), want[k]), k
+    with _h5.File(tmp_path / "metrics.h5") as f:
+        names = f.dataset_names()
+        assert set(mem.names()) <= set(names)
+        steps, _ = mem.column("loss")
+        assert np.array_equal(f["steps"][:], steps)
+        for k in mem.names():
+            col = f[k][:]
+            _, v = mem.column(k)
+            if col.dtype == np.int64:
+                v = np.where(np.isnan(v), -2.0 ** 63, v).astype(np.int64)
+            assert np.array_equal(col, v, equal_nan=col.dtype != np.int64), k
+        assert f["acceptance/rejected"].dtype == np.int64
+    s = storage.load_samples(tmp_path / "samples.h5")
+    assert s["steps"].tolist() == [17, 34]
