@@ -224,7 +224,7 @@ def main():
         all_b = list(pool.index_batches()) if fused else list(pool)
         opt = runner.optimizer
 
-        def one_sample(step):
+        def one_sample(step, reject=True):
             for i, (x, y) in enumerate(all_b):
                 step += 1
                 runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
@@ -234,9 +234,10 @@ def main():
             de = runner._delta_energy(potential)
             de = de.item() if isinstance(de, torch.Tensor) else de
             runner._initial_potential = potential.item()
-            opt.maybe_reject(de)
+            if reject:
+                opt.maybe_reject(de)
             runner.scheduler.step()
-            opt.initial_step(calc_metrics=False, save_state=True)
+            opt.initial_step(calc_metrics=False, save_state=reject)
             return step
 
         step = one_sample(step)          # untimed: first use of the ragged last minibatch etc.
@@ -246,6 +247,14 @@ def main():
             step = one_sample(step)
         torch.cuda.synchronize(device)
         samples = args.samples / (time.perf_counter() - ts)
+        # the paper's default, reject_samples=False: no state snapshot at initial_step, no M-H test
+        samples_noreject = None
+        if runner.reject_samples:
+            ts = time.perf_counter()
+            for _ in range(args.samples):
+                step = one_sample(step, reject=False)
+            torch.cuda.synchronize(device)
+            samples_noreject = args.samples / (time.perf_counter() - ts)
     out = {
         "metric": f"leapfrog steps/sec, {args.inference}", "value": round(world * args.steps / dt, 2),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,7 +268,9 @@ def main():
     }
     if samples is not None:
         out["samples_per_sec"] = {"value": round(world * samples, 3), "per_chain": round(samples, 3),
-                                  "leapfrog_steps_per_sample": L,
+                                  "leapfrog_steps_per_sample": L, "reject_samples": runner.reject_samples,
+                                  "per_chain_reject_samples_false":
+                                      None if samples_noreject is None else round(samples_noreject, 3),
                                   "includes": "L leapfrog steps, exact full-data gradient pass "
                                               "(N rows), final_step, M-H test, initial_step"}
     if rank == 0:

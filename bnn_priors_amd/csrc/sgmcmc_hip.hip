@@ -590,7 +590,7 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
 // VerletSGLD.delta_energy for the gradient this transition used, so a metric step needs no
 // further reduction launches.
 __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
-  // wave w owns segments seg_begin + w, + 4, ...: its 64 lanes stride over the segment's chunk
+  // wave w owns segments seg_begin + w, + n_waves, ...: its 64 lanes stride over the segment's chunk
   // partials (all loads independent), then a fixed shuffle tree; lane 0 does the bookkeeping.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
   const bool with_lp = (A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS);
@@ -878,7 +878,10 @@ void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sg
                      hipStream_t s) {
   if (A->flags & SGMCMC_DEFER_FINALIZE) return;  // the caller runs it later (sgmcmc_finalize)
   const bool small = A->flags & SGMCMC_SMALL_FINALIZE;
-  const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)), block(kThreads);
+  // small: one workgroup, one wave per segment in flight -- 16 waves once there are more than 4 segments
+  // (every segment costs a chain of dependent loads, so the round count is what matters)
+  const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)),
+      block(small && A->seg_end - A->seg_begin > 4 ? 1024u : (unsigned)kThreads);
   if (Ad) {
     if (small) hipLaunchKernelGGL(finalize_small_kernel_indirect, grid, block, 0, s, *L, Ad);
     else hipLaunchKernelGGL(finalize_step_kernel_indirect, grid, block, 0, s, *L, Ad);

@@ -13,6 +13,7 @@ googleresnet convolutions have no bias and always use ``conv_prior_w``
 (default Normal; ``google_resnet.py:34-43``), BatchNorm affine parameters are
 sampled without a prior.
 """
+import torch
 from torch import nn
 
 from .. import prior
@@ -143,6 +144,37 @@ def ClassificationConvNet(in_channels, img_height, out_features, width, depth=3,
     return ClassificationModel(nn.Sequential(*layers), softmax_temp)
 
 
+class _BatchNorm2d(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` whose ``num_batches_tracked += 1`` is left to the enclosing
+    ``_BNTrunk`` (one fused increment for all layers instead of one tiny launch per layer; with a
+    fixed ``momentum`` the counter is bookkeeping only -- but it is part of every stored sample,
+    so it must count exactly as the reference's layers do)."""
+
+    def forward(self, x):
+        if self.momentum is None or not self.track_running_stats:
+            return super().forward(x)
+        return nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                        self.training, self.momentum, self.eps)
+
+
+class _BNTrunk(nn.Sequential):
+    "a Sequential that advances the batch counters of its ``_BatchNorm2d`` layers once per forward"
+
+    def forward(self, x):
+        out = super().forward(x)
+        if self.training:
+            counters = self.__dict__.get("_bn_counters")
+            if counters is None or any(c is not m.num_batches_tracked for c, m in counters):
+                counters = [(m.num_batches_tracked, m) for m in self.modules()
+                            if isinstance(m, _BatchNorm2d) and m.track_running_stats
+                            and m.momentum is not None]
+                self.__dict__["_bn_counters"] = counters
+            if counters:
+                with torch.no_grad():
+                    torch._foreach_add_([c for c, _ in counters], 1)
+        return out
+
+
 class BasicBlock(nn.Module):
     "conv3x3-BN-ReLU-conv3x3-BN plus identity / 1x1-conv-BN shortcut, ReLU after the sum"
 
@@ -173,7 +205,7 @@ def ResNet(softmax_temp=1., depth=20, num_classes=10, prior_w=prior.Normal, loc_
     conv_kwargs = dict(prior_w=conv_prior_w, loc_w=loc_w, std_w=std_w, prior_b=None,
                        scaling_fn=scaling_fn, weight_prior_params=weight_prior_params,
                        bias_prior_params=bias_prior_params)
-    batchnorm = nn.BatchNorm2d if bn else nn.Identity
+    batchnorm = _BatchNorm2d if bn else nn.Identity
     blocks_per_stack, filters = (depth - 2) // 6, 16
     layers = [Conv2dPrior(3, filters, kernel_size=3, padding=1, stride=1, **conv_kwargs),
               batchnorm(filters), nn.ReLU()]
@@ -188,4 +220,4 @@ def ResNet(softmax_temp=1., depth=20, num_classes=10, prior_w=prior.Normal, loc_
                            prior_b=prior_b, loc_b=loc_b, std_b=std_b, scaling_fn=scaling_fn,
                            weight_prior_params=weight_prior_params,
                            bias_prior_params=bias_prior_params)]
-    return ClassificationModel(nn.Sequential(*layers), softmax_temp=softmax_temp)
+    return ClassificationModel((_BNTrunk if bn else nn.Sequential)(*layers), softmax_temp=softmax_temp)
