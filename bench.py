@@ -137,6 +137,11 @@ def flat_arena_point(log2n, device, iters=20):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print while the run is
+    # going (RCCL announces its library path on stdout) is sent to stderr at the fd level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -303,7 +308,8 @@ def main():
                 "sample": f"{res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
                           "(oracle/: reference-op-order torch-CPU loop, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
