@@ -142,6 +142,11 @@ EXPORTS = {
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_wrw_scratch_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sgmcmc_conv3x3_wrw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -1,0 +1,79 @@
+"""The ResNet trunk's 3x3 convolutions on hand-written fp32-MFMA kernels
+(``csrc/conv_hip.inc``; C ABI ``sgmcmc_conv3x3`` / ``sgmcmc_conv3x3_wrw``), as an autograd
+function: forward, data gradient (the same kernel on transposed + flipped weights) and weight
+gradient (partial slabs + a fixed-order reduction: reproducible bit for bit).
+
+``conv3x3(x, w)`` equals ``F.conv2d(x, w, None, 1, 1)`` up to fp32 summation order for the shapes of
+``SHAPES``; ``supported(...)`` tells the layer whether a call qualifies -- anything else (strided
+and 1x1 convolutions, the 3-channel stem, other dtypes, CPU tensors) stays on ATen/MIOpen.
+Reference: the convolutions of bnn_priors/models/google_resnet.py:34-43 inside the gradient
+evaluation of inference.py:215-223.
+"""
+import os
+
+import torch
+
+from . import _hip
+
+SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
+ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
+
+
+def supported(x, w, bias, stride, padding, dilation, groups):
+    if not ENABLED or bias is not None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    c, hw = x.shape[1], x.shape[2]
+    return ((c, hw) in SHAPES and x.shape[3] == hw and tuple(w.shape) == (c, c, 3, 3)
+            and w.dtype == torch.float32 and groups == 1 and x.shape[0] > 0
+            and _pair(stride) == (1, 1) and _pair(padding) == (1, 1) and _pair(dilation) == (1, 1))
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _run(x, w, transpose_w):
+    y = torch.empty_like(x)
+    err = _hip.lib().sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1],
+                                    x.shape[2], int(transpose_w), _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3")
+    return y
+
+
+def _weight_grad(x, dy):
+    lib = _hip.lib()
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+    dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
+    err = lib.sgmcmc_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n, c, hw,
+                                 _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_wrw")
+    return dw
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        return _run(x, w, False)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _run(dy, w, True) if ctx.needs_input_grad[0] else None
+        dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv3x3(x, w):
+    "3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES"
+    return _Conv3x3.apply(x, w)

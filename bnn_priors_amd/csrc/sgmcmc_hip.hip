@@ -1082,3 +1082,5 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 
 // the fused dense-net kernels share the finalize body above (deferred finalize rides in their launch)
 #include "mlp_hip.inc"
+// the convolutional trunk's fp32-MFMA kernels (googleresnet gradient)
+#include "conv_hip.inc"

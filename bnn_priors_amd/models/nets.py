@@ -16,6 +16,7 @@ sampled without a prior.
 import torch
 from torch import nn
 
+from .. import conv as _conv
 from .. import prior
 from .base import ClassificationModel, RegressionModel
 
@@ -54,7 +55,10 @@ class Conv2d(_PriorBacked):
         self.conv_args = (stride, padding, dilation, groups)
 
     def forward(self, x):
-        return nn.functional.conv2d(x, self.weight, self.bias, *self.conv_args)
+        w, b = self.weight, self.bias
+        if _conv.supported(x, w, b, *self.conv_args):      # the trunk's 3x3s: fp32-MFMA kernels
+            return _conv.conv3x3(x, w)
+        return nn.functional.conv2d(x, w, b, *self.conv_args)
 
 
 def _default_scaling(std, dim):

@@ -310,6 +310,24 @@ int sgmcmc_accumulate_parts(const float* gpart, int n_slices, int64_t stride, do
                             float* out_f32, int64_t n, const float* loss_part,
                             const float* correct_part, double* stats, int first, void* stream);
 
+/* 3x3, stride 1, zero-pad 1 convolution of the ResNet trunk on the fp32 matrix pipe, NCHW fp32,
+ * `channels` -> `channels` (16 @ 32x32, 32 @ 16x16, 64 @ 8x8; anything else: hipErrorInvalidValue
+ * and the caller keeps the shape on its library path).  Replaces the convolution inside
+ * autograd's forward / backward of R1 (inference.py:215-223; models/google_resnet.py:34-43):
+ *   transpose_w = 0:  y[n,co,p]  = sum_{ci,r,s} x[n,ci,p+(r-1,s-1)] w[co,ci,r,s]      (forward)
+ *   transpose_w = 1:  y[n,ci,p]  = sum_{co,r,s} x[n,co,p-(r-1,s-1)] w[co,ci,r,s]      (data gradient,
+ *                     x = the gradient w.r.t. the forward output) */
+int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int channels, int hw,
+                   int transpose_w, void* stream);
+
+/* Weight gradient of the same convolution: dw[co,ci,r,s] = sum_{n,p} dy[n,co,p] x[n,ci,p+(r-1,s-1)].
+ * `scratch` holds sgmcmc_conv3x3_wrw_scratch_floats(...) floats of per-workgroup partial slabs that a
+ * second launch sums in a fixed order (deterministic; no atomics).  -1 / hipErrorInvalidValue for
+ * shapes outside the table above. */
+int64_t sgmcmc_conv3x3_wrw_scratch_floats(int n_img, int channels, int hw);
+int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
+                       int channels, int hw, void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

@@ -1,0 +1,114 @@
+"""fp32-MFMA convolution kernels of the ResNet trunk (csrc/conv_hip.inc) against a float64
+reference of the same operator, through the C ABI and through autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bnn_priors_amd import _hip, conv
+
+SHAPES = sorted(conv.SHAPES)
+
+
+def _data(c, hw, n, seed=0):
+    g = torch.Generator().manual_seed(1000 * c + n + seed)
+    x = torch.randn(n, c, hw, hw, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** .5
+    dy = torch.randn(n, c, hw, hw, generator=g)
+    return x, w, dy
+
+
+def test_supported_is_false_off_the_table():
+    x, w, _ = _data(16, 32, 2)
+    assert not conv.supported(x, w, None, 1, 1, 1, 1)                 # CPU tensor
+    assert not conv.supported(x.double(), w.double(), None, 1, 1, 1, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw", SHAPES)
+@pytest.mark.parametrize("n", [128, 5, 1])
+def test_kernels_match_float64_reference(c, hw, n):
+    "forward, data gradient, weight gradient: error of the order of MIOpen's own (fp32 summation order)"
+    x, w, dy = (t.cuda() for t in _data(c, hw, n))
+    assert conv.supported(x, w, None, 1, 1, 1, 1) and conv.supported(x, w, None, (1, 1), (1, 1), (1, 1), 1)
+    for bad in (dict(stride=2), dict(padding=0), dict(dilation=2), dict(groups=2)):
+        kw = dict(stride=1, padding=1, dilation=1, groups=1, **{}) | bad
+        assert not conv.supported(x, w, None, kw["stride"], kw["padding"], kw["dilation"], kw["groups"])
+    assert not conv.supported(x, w, torch.zeros(c, device="cuda"), 1, 1, 1, 1)
+
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    ref_y = F.conv2d(xd, wd, padding=1)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wd, dyd, padding=1)
+    ref_dw = torch.nn.grad.conv2d_weight(xd, w.shape, dyd, padding=1)
+
+    xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = conv.conv3x3(xg, wg)
+    y.backward(dy)
+    # K = 9c products of O(1) magnitude per output; n*hw*hw of them per weight-gradient element
+    tol_y = 64 * torch.finfo(torch.float32).eps * (9 * c) ** .5
+    assert (y.double() - ref_y).abs().max() <= tol_y * max(1.0, ref_y.abs().max().item())
+    assert (xg.grad.double() - ref_dx).abs().max() <= tol_y * max(1.0, ref_dx.abs().max().item())
+    tol_w = 64 * torch.finfo(torch.float32).eps * (n * hw * hw) ** .5
+    assert (wg.grad.double() - ref_dw).abs().max() <= tol_w * max(1.0, ref_dw.abs().max().item())
+
+    # and the library operator it replaces, same tolerances
+    xl, wl = x.clone().requires_grad_(), w.clone().requires_grad_()
+    F.conv2d(xl, wl, padding=1).backward(dy)
+    torch.testing.assert_close(y.detach(), F.conv2d(x, w, padding=1), rtol=1e-4, atol=tol_y * 8)
+    torch.testing.assert_close(xg.grad, xl.grad, rtol=1e-4, atol=tol_y * 8)
+    torch.testing.assert_close(wg.grad, wl.grad, rtol=1e-4, atol=tol_w * 8 * ref_dw.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_gradients_are_reproducible_and_inputs_untouched():
+    x, w, dy = (t.cuda() for t in _data(32, 16, 37))
+    outs = []
+    for _ in range(3):
+        xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = conv.conv3x3(xg, wg)
+        y.backward(dy)
+        outs.append((y.detach(), xg.grad, wg.grad))
+        assert torch.equal(xg.detach(), x) and torch.equal(wg.detach(), w)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    with torch.no_grad():
+        assert torch.equal(conv.conv3x3(x, w), outs[0][0])
+
+
+@pytest.mark.gpu
+def test_abi_rejects_shapes_outside_the_table():
+    lib = _hip.lib()
+    x = torch.zeros(2, 48, 16, 16, device="cuda")
+    w = torch.zeros(48, 48, 3, 3, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 48, 16, 0, st) != 0
+    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 0, 16, 32, 0, st) != 0
+    assert lib.sgmcmc_conv3x3(0, w.data_ptr(), x.data_ptr(), 2, 16, 32, 0, st) != 0
+    assert lib.sgmcmc_conv3x3_wrw_scratch_floats(2, 48, 16) == -1
+    assert lib.sgmcmc_conv3x3_wrw_scratch_floats(3, 16, 32) == 6 * 16 * 16 * 9
+    assert lib.sgmcmc_conv3x3_wrw(x.data_ptr(), x.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 48, 16, st) != 0
+
+
+@pytest.mark.gpu
+def test_resnet_layers_take_the_kernel_path(monkeypatch):
+    "the googleresnet trunk routes its 16 stride-1 3x3 convolutions through conv3x3; switch = env/flag"
+    from bnn_priors_amd import models
+    calls = []
+    real = conv.conv3x3
+    monkeypatch.setattr(conv, "conv3x3", lambda x, w: (calls.append(tuple(x.shape[1:3])), real(x, w))[1])
+    torch.manual_seed(0)
+    x = torch.randn(4, 3, 32, 32)
+    y = torch.randint(0, 10, (4,))
+    net = models.get_model(x, y, "googleresnet", width=50, depth=3, weight_prior="gaussian", weight_loc=0.,
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_loc=0., bias_scale=1.,
+                           batchnorm=True, weight_prior_params={}, bias_prior_params={}).cuda()
+    out = net.net(x.cuda())
+    assert sorted(calls) == [(16, 32)] * 6 + [(32, 16)] * 5 + [(64, 8)] * 5
+    monkeypatch.setattr(conv, "ENABLED", False)
+    calls.clear()
+    net.eval()
+    ref = net.net(x.cuda())
+    assert not calls
+    monkeypatch.setattr(conv, "ENABLED", True)
+    torch.testing.assert_close(net.net(x.cuda()), ref, rtol=1e-4, atol=1e-4)
+    assert out.shape == (4, 10)
