@@ -1,0 +1,77 @@
+"""Training-mode BatchNorm2d fused with the residual add and ReLU that follow it in the ResNet
+trunk, on hand-written HIP kernels (``csrc/bn_hip.inc``; C ABI ``sgmcmc_bn_train_fwd/_bwd``).
+
+``bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False)``
+equals ``relu?(F.batch_norm(x, ..., training=True) [+ residual])`` up to fp32 rounding, updates
+the running statistics like ``nn.BatchNorm2d`` and is differentiable in x, weight, bias and
+residual.  Two launches forward, two backward, deterministic statistics (no atomics).
+Reference: the BatchNorm layers of bnn_priors/models/google_resnet.py:34-43, 77-90.
+"""
+import os
+
+import torch
+
+from . import _hip
+
+ENABLED = os.environ.get("SGMCMC_BN", "1") != "0"
+
+
+def supported(x, weight, bias, training, momentum):
+    return (ENABLED and training and momentum is not None and weight is not None and bias is not None
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and weight.dtype == torch.float32)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class _BNTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+        lib = _hip.lib()
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        y = torch.empty_like(x)
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+        err = lib.sgmcmc_bn_train_fwd(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(),
+                                      _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                      int(relu), n, c, plane, y.data_ptr(), stats[0].data_ptr(),
+                                      stats[1].data_ptr(), scratch.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+        if err:
+            _hip.check(err, "sgmcmc_bn_train_fwd")
+        ctx.save_for_backward(x, weight, y if relu else None, stats)
+        ctx.relu, ctx.has_residual = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = _hip.lib()
+        x, weight, y, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        dx = torch.empty_like(x)
+        want_res = ctx.has_residual and ctx.needs_input_grad[3]
+        if want_res and not ctx.relu:
+            dres = dy                    # no mask: the residual's gradient IS dy
+        else:
+            dres = torch.empty_like(x) if want_res else None
+        dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+        err = lib.sgmcmc_bn_train_bwd(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu), n, c, plane,
+                                      dx.data_ptr(), 0 if dres is dy else _ptr(dres), dwb[0].data_ptr(),
+                                      dwb[1].data_ptr(), scratch.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+        if err:
+            _hip.check(err, "sgmcmc_bn_train_bwd")
+        return dx, dwb[0], dwb[1], dres, None, None, None, None, None
+
+
+def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
+    return _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)

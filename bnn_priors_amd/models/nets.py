@@ -16,6 +16,7 @@ sampled without a prior.
 import torch
 from torch import nn
 
+from .. import bn as _bn
 from .. import conv as _conv
 from .. import prior
 from .base import ClassificationModel, RegressionModel
@@ -155,17 +156,34 @@ class _BatchNorm2d(nn.BatchNorm2d):
     so it must count exactly as the reference's layers do)."""
 
     def forward(self, x):
+        return self.fused(x)
+
+    def fused(self, x, residual=None, relu=False):
+        "relu?(BN(x) [+ residual]): one fused HIP operator in training mode (bn.py), ATen otherwise"
+        if self.track_running_stats and _bn.supported(x, self.weight, self.bias, self.training, self.momentum):
+            return _bn.bn_train(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                self.momentum, self.eps, residual, relu)
         if self.momentum is None or not self.track_running_stats:
-            return super().forward(x)
-        return nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
-                                        self.training, self.momentum, self.eps)
+            y = super().forward(x)
+        else:
+            y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                         self.training, self.momentum, self.eps)
+        if residual is not None:
+            y = y + residual
+        return nn.functional.relu(y) if relu else y
 
 
 class _BNTrunk(nn.Sequential):
     "a Sequential that advances the batch counters of its ``_BatchNorm2d`` layers once per forward"
 
     def forward(self, x):
-        out = super().forward(x)
+        out, mods, i = x, list(self), 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, _BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                out, i = m.fused(out, relu=True), i + 2          # BN + ReLU in one operator
+            else:
+                out, i = m(out), i + 1
         if self.training:
             counters = self.__dict__.get("_bn_counters")
             if counters is None or any(c is not m.num_batches_tracked for c, m in counters):
@@ -198,7 +216,11 @@ class BasicBlock(nn.Module):
                 batchnorm(filters))
 
     def forward(self, x):
-        return nn.functional.relu(self.main(x) + self.shortcut(x))
+        m = self.main
+        if isinstance(m[1], _BatchNorm2d):        # conv, BN+ReLU, conv, BN + shortcut + ReLU
+            h = m[1].fused(m[0](x), relu=True)
+            return m[4].fused(m[3](h), residual=self.shortcut(x), relu=True)
+        return nn.functional.relu(m(x) + self.shortcut(x))
 
 
 def ResNet(softmax_temp=1., depth=20, num_classes=10, prior_w=prior.Normal, loc_w=0.,

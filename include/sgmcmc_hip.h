@@ -328,6 +328,26 @@ int64_t sgmcmc_conv3x3_wrw_scratch_floats(int n_img, int channels, int hw);
 int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                        int channels, int hw, void* stream);
 
+/* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
+ * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
+ * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):
+ *   y = relu?(gamma * (x - mean) * invstd + beta [+ residual]);  save_mean / save_invstd [channels] are
+ *   written for the backward; running_mean / running_var (both or neither) get nn.BatchNorm2d's momentum
+ *   update with the unbiased batch variance.  `plane` = H*W must be a multiple of 4.
+ * Backward: dz = dy * (y > 0) when relu;  dresidual (optional) = dz;  dbeta = sum dz;
+ *   dgamma = sum dz * xhat;  dx = gamma * invstd * (dz - dbeta/M - xhat * dgamma/M).
+ * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane) doubles of per-slice partial sums, combined in
+ * a fixed order (deterministic). */
+int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane);
+int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, double momentum, double eps, int relu,
+                        int n, int channels, int plane, float* y, float* save_mean, float* save_invstd,
+                        double* scratch, void* stream);
+int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const float* gamma,
+                        const float* save_mean, const float* save_invstd, int relu, int n, int channels,
+                        int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,
+                        double* scratch, void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

@@ -1,0 +1,106 @@
+"""Fused training-mode BatchNorm (+ residual + ReLU) kernels (csrc/bn_hip.inc) against ATen's
+batch_norm / add / relu in float64, forward and backward, including the running statistics."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bnn_priors_amd import bn
+
+
+def _ref(x, w, b, rm, rv, res, relu, momentum=0.1, eps=1e-5, mask=None):
+    """float64 reference; ``mask``: use THIS ReLU pattern (the fp32 output's) instead of the float64 one --
+    a pre-activation of 1e-8 may land on either side of zero, and one flipped element moves its whole
+    channel's gradient sums"""
+    y = F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+    if res is not None:
+        y = y + res
+    if not relu:
+        return y
+    return F.relu(y) if mask is None else y * mask
+
+
+def test_supported_is_false_on_cpu_and_in_eval_mode():
+    x, w = torch.zeros(2, 4, 8, 8), torch.ones(4)
+    assert not bn.supported(x, w, w, True, 0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,hw", [(128, 16, 32), (128, 32, 16), (128, 64, 8), (5, 16, 32), (1, 64, 8), (37, 3, 6)])
+@pytest.mark.parametrize("relu,residual", [(True, False), (True, True), (False, False), (False, True)])
+def test_fused_bn_matches_aten(n, c, hw, relu, residual):
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = (torch.randn(n, c, hw, hw, generator=g) * 1.7 + 0.4).cuda()
+    res = torch.randn(n, c, hw, hw, generator=g).cuda() if residual else None
+    w = (torch.rand(c, generator=g) + 0.5).cuda()
+    b = torch.randn(c, generator=g).cuda()
+    dy = torch.randn(n, c, hw, hw, generator=g).cuda()
+    rm0, rv0 = torch.randn(c, generator=g).cuda(), (torch.rand(c, generator=g) + 0.5).cuda()
+    assert bn.supported(x, w, b, True, 0.1) and not bn.supported(x, w, b, False, 0.1)
+    assert not bn.supported(x, w, b, True, None) and not bn.supported(x.double(), w, b, True, 0.1)
+
+    leaves = [t.clone().requires_grad_() for t in (x, w, b)] + ([res.clone().requires_grad_()] if residual else [])
+    rm, rv = rm0.clone(), rv0.clone()
+    y = bn.bn_train(leaves[0], leaves[1], leaves[2], rm, rv, 0.1, 1e-5, leaves[3] if residual else None, relu)
+    y.backward(dy)
+
+    # float64 reference (with the fp32 output's ReLU pattern)
+    leaves64 = [t.double().requires_grad_() for t in (x, w, b)] + ([res.double().requires_grad_()] if residual else [])
+    rm64, rv64 = rm0.double().clone(), rv0.double().clone()
+    y64 = _ref(leaves64[0], leaves64[1], leaves64[2], rm64, rv64, leaves64[3] if residual else None, relu,
+               mask=(y.detach() > 0).double())
+    y64.backward(dy.double())
+
+    M = n * hw * hw
+    torch.testing.assert_close(y.double(), y64.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(rm.double(), rm64, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rv.double(), rv64, rtol=1e-5, atol=1e-6)
+    if relu:    # the pattern itself: identical to float64's except where the pre-activation is ~1e-7
+        pre = _ref(x.double(), w.double(), b.double(), None, None, res.double() if residual else None, False)
+        flipped = (y > 0) != (pre > 0)
+        assert flipped.sum() <= 8 and (pre[flipped].abs() < 1e-5).all()
+    torch.testing.assert_close(leaves[0].grad.double(), leaves64[0].grad, rtol=2e-4, atol=2e-5 + 2e-4 / M ** .5)
+    scale = M ** .5
+    torch.testing.assert_close(leaves[1].grad.double(), leaves64[1].grad, rtol=1e-4, atol=3e-5 * scale)
+    torch.testing.assert_close(leaves[2].grad.double(), leaves64[2].grad, rtol=1e-4, atol=3e-5 * scale)
+    if residual:
+        torch.testing.assert_close(leaves[3].grad.double(), leaves64[3].grad, rtol=1e-6, atol=1e-6)
+
+    # reproducible bit for bit
+    leaves2 = [t.clone().requires_grad_() for t in (x, w, b)] + ([res.clone().requires_grad_()] if residual else [])
+    y2 = bn.bn_train(leaves2[0], leaves2[1], leaves2[2], rm0.clone(), rv0.clone(), 0.1, 1e-5,
+                     leaves2[3] if residual else None, relu)
+    y2.backward(dy)
+    assert torch.equal(y2, y)
+    for a, bb in zip(leaves, leaves2):
+        assert torch.equal(a.grad, bb.grad)
+
+
+@pytest.mark.gpu
+def test_resnet_forward_backward_matches_the_library_path(monkeypatch):
+    "whole googleresnet: fused conv / BN operators on vs off -- same loss, gradients, running statistics"
+    from bnn_priors_amd import conv, models
+    torch.manual_seed(0)
+    x = torch.randn(16, 3, 32, 32)
+    y = torch.randint(0, 10, (16,))
+
+    def run(on):
+        monkeypatch.setattr(conv, "ENABLED", on)
+        monkeypatch.setattr(bn, "ENABLED", on)
+        torch.manual_seed(1)
+        net = models.get_model(x, y, "googleresnet", width=50, depth=3, weight_prior="gaussian", weight_loc=0.,
+                               weight_scale=2 ** .5, bias_prior="gaussian", bias_loc=0., bias_scale=1.,
+                               batchnorm=True, weight_prior_params={}, bias_prior_params={}).cuda()
+        net.train()
+        loss = F.cross_entropy(net.net(x.cuda()), y.cuda())
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+        return loss.item(), grads, {k: v.clone() for k, v in net.state_dict().items()}
+
+    l1, g1, s1 = run(True)
+    l0, g0, s0 = run(False)
+    assert abs(l1 - l0) < 1e-4 * max(1.0, abs(l0))
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=2e-3, atol=2e-4 * max(1.0, g0[k].abs().max().item()), msg=k)
+    for k in s0:
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(s1[k], s0[k], rtol=1e-4, atol=1e-5, msg=k)
