@@ -142,14 +142,16 @@ EXPORTS = {
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_stat_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_conv3x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
     "sgmcmc_conv3x3_wrw_scratch_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_conv3x3_wrw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
-                            + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5),
+                            + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,

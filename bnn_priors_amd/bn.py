@@ -4,7 +4,8 @@ trunk, on hand-written HIP kernels (``csrc/bn_hip.inc``; C ABI ``sgmcmc_bn_train
 ``bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False)``
 equals ``relu?(F.batch_norm(x, ..., training=True) [+ residual])`` up to fp32 rounding, updates
 the running statistics like ``nn.BatchNorm2d`` and is differentiable in x, weight, bias and
-residual.  Two launches forward, two backward, deterministic statistics (no atomics).
+residual.  Two launches forward (one when the producing convolution hands over the batch statistics), two
+backward, deterministic statistics (no atomics).
 Reference: the BatchNorm layers of bnn_priors/models/google_resnet.py:34-43, 77-90.
 """
 import os
@@ -28,7 +29,7 @@ def _ptr(t):
 
 class _BNTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats_in):
         lib = _hip.lib()
         x = x.contiguous()
         if residual is not None:
@@ -36,11 +37,18 @@ class _BNTrain(torch.autograd.Function):
         n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
         y = torch.empty_like(x)
         stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+        scratch = None
+        if stats_in is None:
+            scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64,
+                                  device=x.device)
+        elif stats_in.dtype != torch.float64 or stats_in.dim() != 3 or stats_in.shape[0] != c \
+                or stats_in.shape[2] != 2 or not stats_in.is_contiguous():
+            raise ValueError("stats must be a contiguous float64 [channels][slices][2] tensor")
         err = lib.sgmcmc_bn_train_fwd(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(),
                                       _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
                                       int(relu), n, c, plane, y.data_ptr(), stats[0].data_ptr(),
-                                      stats[1].data_ptr(), scratch.data_ptr(),
+                                      stats[1].data_ptr(), _ptr(scratch), _ptr(stats_in),
+                                      0 if stats_in is None else stats_in.shape[1],
                                       torch.cuda.current_stream().cuda_stream)
         if err:
             _hip.check(err, "sgmcmc_bn_train_fwd")
@@ -70,8 +78,11 @@ class _BNTrain(torch.autograd.Function):
                                       torch.cuda.current_stream().cuda_stream)
         if err:
             _hip.check(err, "sgmcmc_bn_train_bwd")
-        return dx, dwb[0], dwb[1], dres, None, None, None, None, None
+        return dx, dwb[0], dwb[1], dres, None, None, None, None, None, None
 
 
-def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
-    return _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
+def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, stats=None):
+    """``stats``: per-slice partial (sum, sum of squares) of x over (N, H, W) per channel, float64
+    [channels][slices][2], if the producer of x already has them (``conv.conv3x3(..., want_stats=True)``);
+    the statistics pass over x is skipped then."""
+    return _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)

@@ -36,13 +36,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _run(x, w, transpose_w):
+def _run(x, w, transpose_w, want_stats=False):
+    lib = _hip.lib()
     y = torch.empty_like(x)
-    err = _hip.lib().sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1],
-                                    x.shape[2], int(transpose_w), _stream())
+    stats = None
+    if want_stats:   # [channels][slices][2] partial (sum, sum of squares) of y, for the BatchNorm that follows
+        slices = lib.sgmcmc_conv3x3_stat_slices(x.shape[0], x.shape[1], x.shape[2])
+        stats = torch.empty((x.shape[1], slices, 2), dtype=torch.float64, device=x.device)
+    err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
+                             int(transpose_w), 0 if stats is None else stats.data_ptr(), _stream())
     if err:
         _hip.check(err, "sgmcmc_conv3x3")
-    return y
+    return y, stats
 
 
 def _weight_grad(x, dy):
@@ -59,21 +64,27 @@ def _weight_grad(x, dy):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, want_stats):
         x, w = x.contiguous(), w.contiguous()
         ctx.save_for_backward(x, w)
-        return _run(x, w, False)
+        y, stats = _run(x, w, False, want_stats)
+        if not want_stats:
+            return y
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = _run(dy, w, True) if ctx.needs_input_grad[0] else None
+        dx = _run(dy, w, True)[0] if ctx.needs_input_grad[0] else None
         dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3(x, w):
-    "3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES"
-    return _Conv3x3.apply(x, w)
+def conv3x3(x, w, want_stats=False):
+    """3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES.
+    ``want_stats``: also return the per-band (sum, sum of squares) of every output channel, float64
+    [channels][slices][2] -- what ``bn.bn_train(..., stats=...)`` needs instead of a pass over y."""
+    return _Conv3x3.apply(x, w, want_stats)

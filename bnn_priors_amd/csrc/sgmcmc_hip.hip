@@ -24,6 +24,11 @@
 
 #include "sgmcmc_hip.h"
 
+// Every entry point reports ITS launches through hipGetLastError().  That state is process-wide and
+// sticky: a failed pointer query inside another library (ATen's pinned-memory checks leave
+// hipErrorInvalidValue behind) would otherwise surface here as if one of our launches had failed.
+#define SGMCMC_FRESH_ERROR_STATE() (void)hipGetLastError()
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -594,6 +599,8 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
   // partials (all loads independent), then a fixed shuffle tree; lane 0 does the bookkeeping.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
   const bool with_lp = (A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS);
+  constexpr int kSmallSegs = 256;
+  __shared__ double seg_e[kSmallSegs], seg_lp[kSmallSegs];  // each segment's energy term / log-prior
   for (int seg = A.seg_begin + wave; seg < A.seg_end; seg += n_waves) {
     const sgmcmc_segment s = L.segs[seg];
     const int64_t n = seg_chunks(L, s);
@@ -612,17 +619,26 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
     }
     if (lane == 0) {
       double S6[SGMCMC_NSUMS] = {S[0], S[1], S[2], S[3], S[4], S[5]};
-      segment_bookkeeping(L, A, seg, s, S6);
+      const double e = segment_bookkeeping(L, A, seg, s, S6);
+      double lp = 0.0;
       if (with_lp)
-        L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s);
+        L.state[seg].aux = lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s);
+      if (seg - A.seg_begin < kSmallSegs) { seg_e[seg - A.seg_begin] = e; seg_lp[seg - A.seg_begin] = lp; }
     }
   }
   __syncthreads();  // the per-segment results written above are visible to thread 0 below
   if (threadIdx.x == 0) {
     double total = 0.0, lp_total = 0.0;  // segment order, as the reference's Python loop
-    for (int seg = A.seg_begin; seg < A.seg_end; ++seg) {
-      total += L.state[seg].delta_energy + L.state[seg].point_energy;
-      if (with_lp) lp_total += L.state[seg].aux;
+    if (A.seg_end - A.seg_begin <= kSmallSegs) {  // from LDS: 2 x n_seg dependent global loads cost ~0.4 us each
+      for (int i = 0; i < A.seg_end - A.seg_begin; ++i) {
+        total += seg_e[i];
+        if (with_lp) lp_total += seg_lp[i];
+      }
+    } else {
+      for (int seg = A.seg_begin; seg < A.seg_end; ++seg) {
+        total += L.state[seg].delta_energy + L.state[seg].point_energy;
+        if (with_lp) lp_total += L.state[seg].aux;
+      }
     }
     L.scalars[3] = total;
     if (with_lp) L.scalars[2] = lp_total;
@@ -901,6 +917,7 @@ const char* sgmcmc_error_string(int err) { return hipGetErrorString((hipError_t)
 
 int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
                       void* ev_start, void* ev_stop) {
+  SGMCMC_FRESH_ERROR_STATE();
   hipStream_t s = (hipStream_t)stream;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
   const int rc = launch_step(L, A, nullptr, nullptr, s);
@@ -911,11 +928,13 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
 }
 
 int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   return sgmcmc_step_timed(L, A, stream, nullptr, nullptr);
 }
 
 int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,
                          void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!Ad) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const int rc = launch_step(L, A, Ad, nullptr, s);
@@ -926,6 +945,7 @@ int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A, cons
 
 int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A,
                                const sgmcmc_step_args* Ad, const sgmcmc_grad_parts* P, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!Ad || !P || !P->gpart || P->n_slices <= 0 || P->batch <= 0 || !(P->num_data > 0))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -952,6 +972,7 @@ int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
 }
 
 int sgmcmc_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!L || !A || A->seg_end <= A->seg_begin) return (int)hipErrorInvalidValue;
   sgmcmc_step_args B = *A;
   B.flags &= ~(uint32_t)SGMCMC_DEFER_FINALIZE;
@@ -960,6 +981,7 @@ int sgmcmc_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* str
 }
 
 int sgmcmc_event_create(void** ev) {
+  SGMCMC_FRESH_ERROR_STATE();
   hipEvent_t e;
   const hipError_t err = hipEventCreate(&e);
   if (err == hipSuccess) *ev = (void*)e;
@@ -969,6 +991,7 @@ int sgmcmc_event_create(void** ev) {
 int sgmcmc_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 
 int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+  SGMCMC_FRESH_ERROR_STATE();
   hipError_t err = hipEventSynchronize((hipEvent_t)ev_stop);
   if (err != hipSuccess) return (int)err;
   return (int)hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
@@ -976,6 +999,7 @@ int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
 
 int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint64_t seed,
                            uint32_t stream, uint64_t draw, void* stream_) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!L || L->n_chunks <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream_;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
@@ -987,6 +1011,7 @@ int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint
 }
 
 int sgmcmc_restore(const sgmcmc_layout* L, int restore_momentum, uint32_t flags, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   (void)flags;
   if (!L || L->n_chunks <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -1007,6 +1032,7 @@ static int launch_dot(const sgmcmc_layout* L, int which, double clampv, hipStrea
 
 int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, double b2h2,
                         double grad_clamp, uint32_t flags, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   (void)flags;
   if (!L || L->n_chunks <= 0 || (kind != SGMCMC_VERLET && kind != SGMCMC_HMC))
     return (int)hipErrorInvalidValue;
@@ -1020,6 +1046,7 @@ int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, doubl
 }
 
 int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   (void)flags;
   if (!L || L->n_chunks <= 0 || which < 0 || which > 2) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -1031,6 +1058,7 @@ int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* 
 
 int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob, uint32_t flags,
                       void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   (void)flags;
   if (!L || L->n_chunks <= 0 || !(num_data > 0)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -1051,6 +1079,7 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
                              int64_t stride, const float* loss_part, const float* correct_part,
                              int batch, double num_data, uint32_t flags,
                              const sgmcmc_step_args* A_dev, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!L || L->n_chunks <= 0 || !(num_data > 0) || !gpart || n_slices <= 0 || batch <= 0 ||
       L->dtype != SGMCMC_F32)
     return (int)hipErrorInvalidValue;
@@ -1072,6 +1101,7 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
 
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_) {
+  SGMCMC_FRESH_ERROR_STATE();
   if (!out || n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(debug_normals_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, out,
                      start, n, seed, stream, draw, purpose);

@@ -55,11 +55,14 @@ class Conv2d(_PriorBacked):
         self.in_channels, self.kernel_size, self.groups = cin * groups, (kh, kw), groups
         self.conv_args = (stride, padding, dilation, groups)
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
+        """``want_stats``: return (y, stats) where stats is what ``bn.bn_train(stats=...)`` takes (the
+        per-channel batch statistics of y, from the kernel's accumulators) or None on the library path"""
         w, b = self.weight, self.bias
         if _conv.supported(x, w, b, *self.conv_args):      # the trunk's 3x3s: fp32-MFMA kernels
-            return _conv.conv3x3(x, w)
-        return nn.functional.conv2d(x, w, b, *self.conv_args)
+            return _conv.conv3x3(x, w, want_stats)
+        y = nn.functional.conv2d(x, w, b, *self.conv_args)
+        return (y, None) if want_stats else y
 
 
 def _default_scaling(std, dim):
@@ -158,11 +161,11 @@ class _BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x):
         return self.fused(x)
 
-    def fused(self, x, residual=None, relu=False):
+    def fused(self, x, residual=None, relu=False, stats=None):
         "relu?(BN(x) [+ residual]): one fused HIP operator in training mode (bn.py), ATen otherwise"
         if self.track_running_stats and _bn.supported(x, self.weight, self.bias, self.training, self.momentum):
             return _bn.bn_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                self.momentum, self.eps, residual, relu)
+                                self.momentum, self.eps, residual, relu, stats)
         if self.momentum is None or not self.track_running_stats:
             y = super().forward(x)
         else:
@@ -173,6 +176,18 @@ class _BatchNorm2d(nn.BatchNorm2d):
         return nn.functional.relu(y) if relu else y
 
 
+def _conv_bn(conv, bn, x, residual=None, relu=False):
+    "relu?(bn(conv(x)) [+ residual]); the convolution's epilogue hands the batch statistics to the BN"
+    if isinstance(conv, Conv2d) and isinstance(bn, _BatchNorm2d):
+        want = bn.training and bn.track_running_stats and _bn.ENABLED
+        y, stats = conv(x, want_stats=True) if want else (conv(x), None)
+        return bn.fused(y, residual, relu, stats)
+    y = bn(conv(x))
+    if residual is not None:
+        y = y + residual
+    return nn.functional.relu(y) if relu else y
+
+
 class _BNTrunk(nn.Sequential):
     "a Sequential that advances the batch counters of its ``_BatchNorm2d`` layers once per forward"
 
@@ -180,7 +195,10 @@ class _BNTrunk(nn.Sequential):
         out, mods, i = x, list(self), 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, _BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            if (isinstance(m, Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], _BatchNorm2d)
+                    and isinstance(mods[i + 2], nn.ReLU)):
+                out, i = _conv_bn(m, mods[i + 1], out, relu=True), i + 3     # conv, BN + ReLU
+            elif isinstance(m, _BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 out, i = m.fused(out, relu=True), i + 2          # BN + ReLU in one operator
             else:
                 out, i = m(out), i + 1
@@ -218,8 +236,10 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         m = self.main
         if isinstance(m[1], _BatchNorm2d):        # conv, BN+ReLU, conv, BN + shortcut + ReLU
-            h = m[1].fused(m[0](x), relu=True)
-            return m[4].fused(m[3](h), residual=self.shortcut(x), relu=True)
+            h = _conv_bn(m[0], m[1], x, relu=True)
+            sc = self.shortcut
+            skip = _conv_bn(sc[0], sc[1], x) if isinstance(sc, nn.Sequential) else sc(x)
+            return _conv_bn(m[3], m[4], h, residual=skip, relu=True)
         return nn.functional.relu(m(x) + self.shortcut(x))
 
 

@@ -316,9 +316,13 @@ int sgmcmc_accumulate_parts(const float* gpart, int n_slices, int64_t stride, do
  * autograd's forward / backward of R1 (inference.py:215-223; models/google_resnet.py:34-43):
  *   transpose_w = 0:  y[n,co,p]  = sum_{ci,r,s} x[n,ci,p+(r-1,s-1)] w[co,ci,r,s]      (forward)
  *   transpose_w = 1:  y[n,ci,p]  = sum_{co,r,s} x[n,co,p-(r-1,s-1)] w[co,ci,r,s]      (data gradient,
- *                     x = the gradient w.r.t. the forward output) */
+ *                     x = the gradient w.r.t. the forward output)
+ *   stats (forward only, may be NULL): [channels][sgmcmc_conv3x3_stat_slices(...)][2] doubles, the
+ *   per-band (sum y, sum y^2) of every output channel -- the batch statistics of the BatchNorm that
+ *   follows, taken from the accumulators (pass them to sgmcmc_bn_train_fwd as stats_in). */
+int sgmcmc_conv3x3_stat_slices(int n_img, int channels, int hw);
 int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int channels, int hw,
-                   int transpose_w, void* stream);
+                   int transpose_w, double* stats, void* stream);
 
 /* Weight gradient of the same convolution: dw[co,ci,r,s] = sum_{n,p} dy[n,co,p] x[n,ci,p+(r-1,s-1)].
  * `scratch` holds sgmcmc_conv3x3_wrw_scratch_floats(...) floats of per-workgroup partial slabs that a
@@ -337,12 +341,13 @@ int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratc
  * Backward: dz = dy * (y > 0) when relu;  dresidual (optional) = dz;  dbeta = sum dz;
  *   dgamma = sum dz * xhat;  dx = gamma * invstd * (dz - dbeta/M - xhat * dgamma/M).
  * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane) doubles of per-slice partial sums, combined in
- * a fixed order (deterministic). */
+ * a fixed order (deterministic).  Forward: when `stats_in` ([channels][stats_slices][2] partial (sum, sum of
+ * squares) of x, e.g. from sgmcmc_conv3x3) is given, the statistics pass over x is skipped. */
 int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane);
 int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, double momentum, double eps, int relu,
                         int n, int channels, int plane, float* y, float* save_mean, float* save_invstd,
-                        double* scratch, void* stream);
+                        double* scratch, const double* stats_in, int stats_slices, void* stream);
 int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const float* gamma,
                         const float* save_mean, const float* save_invstd, int relu, int n, int channels,
                         int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,

@@ -81,9 +81,9 @@ def test_abi_rejects_shapes_outside_the_table():
     x = torch.zeros(2, 48, 16, 16, device="cuda")
     w = torch.zeros(48, 48, 3, 3, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 48, 16, 0, st) != 0
-    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 0, 16, 32, 0, st) != 0
-    assert lib.sgmcmc_conv3x3(0, w.data_ptr(), x.data_ptr(), 2, 16, 32, 0, st) != 0
+    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 48, 16, 0, 0, st) != 0
+    assert lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), x.data_ptr(), 0, 16, 32, 0, 0, st) != 0
+    assert lib.sgmcmc_conv3x3(0, w.data_ptr(), x.data_ptr(), 2, 16, 32, 0, 0, st) != 0
     assert lib.sgmcmc_conv3x3_wrw_scratch_floats(2, 48, 16) == -1
     assert lib.sgmcmc_conv3x3_wrw_scratch_floats(3, 16, 32) == 6 * 16 * 16 * 9
     assert lib.sgmcmc_conv3x3_wrw(x.data_ptr(), x.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 48, 16, st) != 0
@@ -95,7 +95,8 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
     from bnn_priors_amd import models
     calls = []
     real = conv.conv3x3
-    monkeypatch.setattr(conv, "conv3x3", lambda x, w: (calls.append(tuple(x.shape[1:3])), real(x, w))[1])
+    monkeypatch.setattr(conv, "conv3x3",
+                        lambda x, w, want_stats=False: (calls.append(tuple(x.shape[1:3])), real(x, w, want_stats))[1])
     torch.manual_seed(0)
     x = torch.randn(4, 3, 32, 32)
     y = torch.randint(0, 10, (4,))
@@ -112,3 +113,29 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
     monkeypatch.setattr(conv, "ENABLED", True)
     torch.testing.assert_close(net.net(x.cuda()), ref, rtol=1e-4, atol=1e-4)
     assert out.shape == (4, 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw", SHAPES)
+def test_epilogue_statistics_feed_the_batchnorm(c, hw):
+    "conv3x3(want_stats=True): per-band sums of y; bn_train(stats=...) == bn_train() on the same y"
+    from bnn_priors_amd import bn
+    x, w, _ = (t.cuda() for t in _data(c, hw, 19))
+    y, stats = conv.conv3x3(x, w, want_stats=True)
+    assert torch.equal(y, conv.conv3x3(x, w))
+    assert stats.shape == (c, 19 * hw // 8, 2) and stats.dtype == torch.float64
+    yd = y.double()
+    torch.testing.assert_close(stats[:, :, 0].sum(1), yd.sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-4)
+    torch.testing.assert_close(stats[:, :, 1].sum(1), (yd * yd).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-4)
+    band = yd.view(19, c, hw // 8, 8 * hw).sum(-1).permute(1, 0, 2).reshape(c, -1)     # [c][img*bands + band]
+    torch.testing.assert_close(stats[:, :, 0], band, rtol=1e-5, atol=1e-4)
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    outs = []
+    for st in (None, stats):
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        outs.append((bn.bn_train(y, gamma, beta, rm, rv, 0.1, 1e-5, None, True, st), rm, rv))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError, match="stats"):
+        bn.bn_train(y, gamma, beta, None, None, 0.1, 1e-5, None, True, stats.float())

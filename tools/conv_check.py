@@ -8,6 +8,8 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from bnn_priors_amd import _hip
 
+if len(sys.argv) > 1:
+    _hip.LIB_PATH = sys.argv[1]      # an experimental build
 lib = _hip.lib()
 dev = "cuda:0"
 torch.backends.cudnn.benchmark = True
@@ -29,7 +31,7 @@ def timeit(fn, n=200):
 def conv(x, w, transpose):
     y = torch.empty_like(x)
     err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
-                             int(transpose), torch.cuda.current_stream().cuda_stream)
+                             int(transpose), 0, torch.cuda.current_stream().cuda_stream)
     assert err == 0, err
     return y
 
