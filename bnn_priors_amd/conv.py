@@ -62,6 +62,19 @@ def _weight_grad(x, dy):
     return dw
 
 
+def _both_grads(x, w, dy):
+    lib = _hip.lib()
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
+    err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                 scratch.data_ptr(), n, c, hw, _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_bwd")
+    return dx, dw
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, want_stats):
@@ -78,6 +91,8 @@ class _Conv3x3(torch.autograd.Function):
     def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            return (*_both_grads(x, w, dy), None)         # one launch for the two of them
         dx = _run(dy, w, True)[0] if ctx.needs_input_grad[0] else None
         dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
         return dx, dw, None

@@ -331,6 +331,11 @@ int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int chan
 int64_t sgmcmc_conv3x3_wrw_scratch_floats(int n_img, int channels, int hw);
 int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                        int channels, int hw, void* stream);
+/* Both gradients in one launch (they are independent and share the GPU): dx as sgmcmc_conv3x3 with
+ * transpose_w = 1 on dy, dw and scratch as sgmcmc_conv3x3_wrw.  Results are bit-identical to the two
+ * separate calls. */
+int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                       float* scratch, int n_img, int channels, int hw, void* stream);
 
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,

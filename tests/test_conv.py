@@ -73,6 +73,12 @@ def test_gradients_are_reproducible_and_inputs_untouched():
             assert torch.equal(a, b)
     with torch.no_grad():
         assert torch.equal(conv.conv3x3(x, w), outs[0][0])
+    # the merged backward launch (data + weight gradient together) == the two separate entry points
+    assert torch.equal(conv._run(dy, w, True)[0], outs[0][1])
+    assert torch.equal(conv._weight_grad(x, dy), outs[0][2])
+    xg, wg = x.clone().requires_grad_(), w.clone()          # only one gradient wanted: separate kernels
+    conv.conv3x3(xg, wg).backward(dy)
+    assert torch.equal(xg.grad, outs[0][1])
 
 
 @pytest.mark.gpu
