@@ -68,6 +68,12 @@ class StepArgs(ctypes.Structure):
                 ("stream", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
+class ReduceJob(ctypes.Structure):
+    "sgmcmc_reduce_job"
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_slabs", ctypes.c_int32),
+                ("numel", ctypes.c_int32)]
+
+
 class GradParts(ctypes.Structure):
     _fields_ = [("gpart", ctypes.c_void_p), ("loss_part", ctypes.c_void_p),
                 ("correct_part", ctypes.c_void_p), ("stride", ctypes.c_int64),
@@ -153,7 +159,9 @@ EXPORTS = {
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
                             + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6),
-    "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
+                           + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_wrw_reduce_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

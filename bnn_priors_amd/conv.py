@@ -9,6 +9,7 @@ and 1x1 convolutions, the 3-channel stem, other dtypes, CPU tensors) stays on AT
 Reference: the convolutions of bnn_priors/models/google_resnet.py:34-43 inside the gradient
 evaluation of inference.py:215-223.
 """
+import ctypes
 import os
 
 import torch
@@ -17,6 +18,7 @@ from . import _hip
 
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
+DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
 
 
 def supported(x, w, bias, stride, padding, dilation, groups):
@@ -62,17 +64,43 @@ def _weight_grad(x, dy):
     return dw
 
 
-def _both_grads(x, w, dy):
+def _both_grads(x, w, dy, defer):
     lib = _hip.lib()
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
+    slabs = ctypes.c_int(0)
     err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                 scratch.data_ptr(), n, c, hw, _stream())
+                                 scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None, _stream())
     if err:
         _hip.check(err, "sgmcmc_conv3x3_bwd")
+    if defer:
+        # autograd gets an ALIAS: AccumulateGrad only adopts a gradient nobody else references, and it
+        # must adopt (not copy) this one -- its memory is filled at the end of the pass
+        _pending.append((scratch, dw, slabs.value))
+        return dx, dw.view(dw.shape)
     return dx, dw
+
+
+# Weight-gradient slabs whose reduction waits for the end of the running backward pass, where ONE launch
+# sums all of them (autograd's final callback).  Only gradients nothing reads before that point are
+# deferred: leaf weights whose .grad is still None (AccumulateGrad then just keeps the tensor).  A tensor
+# hook that READS a convolution weight's gradient during backward would see it unreduced: set
+# SGMCMC_CONV_DEFER=0 (or conv.DEFER_REDUCE = False) in that case.
+_pending = []
+
+
+def _flush_pending():
+    if not _pending:
+        return
+    jobs = (_hip.ReduceJob * len(_pending))()
+    for j, (scratch, dw, slabs) in zip(jobs, _pending):
+        j.part, j.out, j.n_slabs, j.numel = scratch.data_ptr(), dw.data_ptr(), slabs, dw.numel()
+    err = _hip.lib().sgmcmc_wrw_reduce_many(ctypes.cast(jobs, ctypes.c_void_p), len(_pending), _stream())
+    _pending.clear()
+    if err:
+        _hip.check(err, "sgmcmc_wrw_reduce_many")
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -92,7 +120,10 @@ class _Conv3x3(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            return (*_both_grads(x, w, dy), None)         # one launch for the two of them
+            defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+            if defer:   # every deferring call queues it; the first one to run does the work
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+            return (*_both_grads(x, w, dy, defer), None)         # one launch for the two of them
         dx = _run(dy, w, True)[0] if ctx.needs_input_grad[0] else None
         dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
         return dx, dw, None

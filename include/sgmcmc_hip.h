@@ -333,9 +333,19 @@ int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratc
                        int channels, int hw, void* stream);
 /* Both gradients in one launch (they are independent and share the GPU): dx as sgmcmc_conv3x3 with
  * transpose_w = 1 on dy, dw and scratch as sgmcmc_conv3x3_wrw.  Results are bit-identical to the two
- * separate calls. */
+ * separate calls.
+ * With `deferred_slabs` != NULL the slab reduction is NOT launched: *deferred_slabs receives the number of
+ * slabs in `scratch` and the caller sums them later -- typically all weight gradients of a backward pass
+ * in ONE launch of sgmcmc_wrw_reduce_many (same summation order: same bits). */
+#define SGMCMC_REDUCE_JOBS 32
+typedef struct sgmcmc_reduce_job {
+  const float* part; /* [n_slabs][numel] */
+  float* out;        /* [numel] */
+  int32_t n_slabs, numel;
+} sgmcmc_reduce_job;
 int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
-                       float* scratch, int n_img, int channels, int hw, void* stream);
+                       float* scratch, int n_img, int channels, int hw, int* deferred_slabs, void* stream);
+int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,

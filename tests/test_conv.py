@@ -76,6 +76,22 @@ def test_gradients_are_reproducible_and_inputs_untouched():
     # the merged backward launch (data + weight gradient together) == the two separate entry points
     assert torch.equal(conv._run(dy, w, True)[0], outs[0][1])
     assert torch.equal(conv._weight_grad(x, dy), outs[0][2])
+    # accumulation into an existing .grad reads the gradient at once: that route reduces immediately
+    xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+    conv.conv3x3(xg, wg).backward(dy)
+    assert not conv._pending
+    conv.conv3x3(xg, wg).backward(dy)
+    assert not conv._pending
+    assert torch.equal(wg.grad, outs[0][2] + outs[0][2]) and torch.equal(xg.grad, outs[0][1] + outs[0][1])
+    # two convolutions in one backward pass: one deferred launch reduces both
+    x2, w2, w3 = x.clone().requires_grad_(), w.clone().requires_grad_(), (w * 0.5).requires_grad_()
+    conv.conv3x3(conv.conv3x3(x2, w2), w3).backward(dy)
+    torch.cuda.synchronize()
+    assert not conv._pending
+    ref2, ref3 = w.clone().requires_grad_(), (w * 0.5).requires_grad_()
+    F.conv2d(F.conv2d(x, ref2, padding=1), ref3, padding=1).backward(dy)
+    torch.testing.assert_close(w2.grad, ref2.grad, rtol=1e-4, atol=1e-3 * ref2.grad.abs().max().item())
+    torch.testing.assert_close(w3.grad, ref3.grad, rtol=1e-4, atol=1e-3 * ref3.grad.abs().max().item())
     xg, wg = x.clone().requires_grad_(), w.clone()          # only one gradient wanted: separate kernels
     conv.conv3x3(xg, wg).backward(dy)
     assert torch.equal(xg.grad, outs[0][1])
