@@ -162,6 +162,11 @@ EXPORTS = {
     "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
                            + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_wrw_reduce_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv_down_stat_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sgmcmc_conv_down_fwd": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "sgmcmc_conv_down_scratch_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sgmcmc_conv_down_bwd": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 3
+                             + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

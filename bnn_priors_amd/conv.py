@@ -134,3 +134,76 @@ def conv3x3(x, w, want_stats=False):
     ``want_stats``: also return the per-band (sum, sum of squares) of every output channel, float64
     [channels][slices][2] -- what ``bn.bn_train(..., stats=...)`` needs instead of a pass over y."""
     return _Conv3x3.apply(x, w, want_stats)
+
+
+# ------------------------------------------------------------------ the down-sampling block's pair
+DOWN_SHAPES = {(16, 32), (32, 16)}          # (input channels, input side): 3x3 / stride 2 + 1x1 / stride 2
+
+
+def down_supported(x, w_main, w_short):
+    "the two convolutions that open a down-sampling block, as one operator (csrc/conv_down_hip.inc)"
+    if not ENABLED or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[0] == 0:
+        return False
+    c, hw = x.shape[1], x.shape[2]
+    return ((c, hw) in DOWN_SHAPES and x.shape[3] == hw and tuple(w_main.shape) == (2 * c, c, 3, 3)
+            and tuple(w_short.shape) == (2 * c, c, 1, 1) and w_main.dtype == torch.float32
+            and w_short.dtype == torch.float32)
+
+
+class _ConvDown(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_main, w_short, want_stats):
+        lib = _hip.lib()
+        x, w_main, w_short = x.contiguous(), w_main.contiguous(), w_short.contiguous()
+        n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+        ym = torch.empty((n, 2 * c, hw // 2, hw // 2), dtype=torch.float32, device=x.device)
+        ys = torch.empty_like(ym)
+        sm = ss = None
+        if want_stats:
+            slices = lib.sgmcmc_conv_down_stat_slices(n, c, hw)
+            sm = torch.empty((2 * c, slices, 2), dtype=torch.float64, device=x.device)
+            ss = torch.empty_like(sm)
+        err = lib.sgmcmc_conv_down_fwd(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), ym.data_ptr(),
+                                       ys.data_ptr(), 0 if sm is None else sm.data_ptr(),
+                                       0 if ss is None else ss.data_ptr(), n, c, hw, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_down_fwd")
+        ctx.save_for_backward(x, w_main, w_short)
+        if not want_stats:
+            return ym, ys
+        ctx.mark_non_differentiable(sm, ss)
+        return ym, ys, sm, ss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dym, dys, *_):
+        lib = _hip.lib()
+        x, w_main, w_short = ctx.saved_tensors
+        dym, dys = dym.contiguous(), dys.contiguous()
+        n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+        scratch = torch.empty(lib.sgmcmc_conv_down_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dwm, dws = torch.empty_like(w_main), torch.empty_like(w_short)
+        defer = (DEFER_REDUCE and w_main.is_leaf and w_main.grad is None and w_short.is_leaf
+                 and w_short.grad is None)
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv_down_bwd(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
+                                       dys.data_ptr(), dx.data_ptr(), dwm.data_ptr(), dws.data_ptr(),
+                                       scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None,
+                                       _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_down_bwd")
+        if defer:   # scratch = [slabs][dwm.numel()] then [slabs][dws.numel()]
+            _pending.append((scratch, dwm, slabs.value))
+            _pending.append((scratch[slabs.value * dwm.numel():], dws, slabs.value))
+            return dx, dwm.view(dwm.shape), dws.view(dws.shape), None
+        return dx, dwm, dws, None
+
+
+def conv_down(x, w_main, w_short, want_stats=False):
+    """(conv2d(x, w_main, stride=2, padding=1), conv2d(x, w_short, stride=2)) in one operator, for the
+    (channels, side) pairs in DOWN_SHAPES; with ``want_stats`` also the two outputs' batch statistics
+    (see ``conv3x3``)."""
+    return _ConvDown.apply(x, w_main, w_short, want_stats)

@@ -233,12 +233,26 @@ class BasicBlock(nn.Module):
                             **conv_kwargs),
                 batchnorm(filters))
 
+    def _down_fused(self, x):
+        c0, c1 = self.main[0], self.shortcut[0]
+        return (isinstance(c0, Conv2d) and isinstance(c1, Conv2d) and c0.bias is None and c1.bias is None
+                and c0.conv_args == (2, 1, 1, 1) and c1.conv_args == (2, 0, 1, 1)
+                and isinstance(self.shortcut[1], _BatchNorm2d)
+                and _conv.down_supported(x, c0.weight, c1.weight))
+
     def forward(self, x):
         m = self.main
         if isinstance(m[1], _BatchNorm2d):        # conv, BN+ReLU, conv, BN + shortcut + ReLU
-            h = _conv_bn(m[0], m[1], x, relu=True)
             sc = self.shortcut
-            skip = _conv_bn(sc[0], sc[1], x) if isinstance(sc, nn.Sequential) else sc(x)
+            if isinstance(sc, nn.Sequential) and self._down_fused(x):
+                # down-sampling block: the strided 3x3 and the 1x1 shortcut read the same x -- one kernel
+                want = m[1].training and m[1].track_running_stats and _bn.ENABLED
+                ym, ys, *st = _conv.conv_down(x, m[0].weight, sc[0].weight, want)
+                h = m[1].fused(ym, relu=True, stats=st[0] if want else None)
+                skip = sc[1].fused(ys, stats=st[1] if want else None)
+            else:
+                h = _conv_bn(m[0], m[1], x, relu=True)
+                skip = _conv_bn(sc[0], sc[1], x) if isinstance(sc, nn.Sequential) else sc(x)
             return _conv_bn(m[3], m[4], h, residual=skip, relu=True)
         return nn.functional.relu(m(x) + self.shortcut(x))
 

@@ -347,6 +347,26 @@ int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* d
                        float* scratch, int n_img, int channels, int hw, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
+/* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;
+ * the 1x1 shortcut's operand is the 3x3's centre tap): models/google_resnet.py:77-90.
+ *   y_main[n,co,oy,ox]  = sum_{ci,r,s} x[n,ci,2oy+r-1,2ox+s-1] w_main[co,ci,r,s]     (3x3, stride 2, pad 1)
+ *   y_short[n,co,oy,ox] = sum_ci x[n,ci,2oy,2ox] w_short[co,ci]                        (1x1, stride 2)
+ * cin -> 2 cin channels, hwi -> hwi/2 pixels, for (cin, hwi) = (16, 32) and (32, 16).  stats_main /
+ * stats_short (both or neither): [2 cin][sgmcmc_conv_down_stat_slices(...)][2] per-band (sum, sum of
+ * squares) of the two outputs, as for sgmcmc_conv3x3. */
+int sgmcmc_conv_down_stat_slices(int n_img, int cin, int hwi);
+int sgmcmc_conv_down_fwd(const float* x, const float* w_main, const float* w_short, float* y_main,
+                         float* y_short, double* stats_main, double* stats_short, int n_img, int cin,
+                         int hwi, void* stream);
+/* All three gradients in one launch: dx (both paths summed: the transposed convolutions, evaluated per
+ * parity class of the input pixel so that no multiply is spent on zeros), dw_main, dw_short.  `scratch`:
+ * sgmcmc_conv_down_scratch_floats(...) floats, laid out [n_slabs][18 cin^2] then [n_slabs][2 cin^2];
+ * `deferred_slabs` as for sgmcmc_conv3x3_bwd (two jobs for sgmcmc_wrw_reduce_many). */
+int64_t sgmcmc_conv_down_scratch_floats(int n_img, int cin, int hwi);
+int sgmcmc_conv_down_bwd(const float* x, const float* w_main, const float* w_short, const float* dy_main,
+                         const float* dy_short, float* dx, float* dw_main, float* dw_short, float* scratch,
+                         int n_img, int cin, int hwi, int* deferred_slabs, void* stream);
+
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
  * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):

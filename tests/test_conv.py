@@ -125,13 +125,19 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
     net = models.get_model(x, y, "googleresnet", width=50, depth=3, weight_prior="gaussian", weight_loc=0.,
                            weight_scale=2 ** .5, bias_prior="gaussian", bias_loc=0., bias_scale=1.,
                            batchnorm=True, weight_prior_params={}, bias_prior_params={}).cuda()
+    downs = []
+    real_down = conv.conv_down
+    monkeypatch.setattr(conv, "conv_down", lambda x, wm, ws, want_stats=False:
+                        (downs.append(tuple(x.shape[1:3])), real_down(x, wm, ws, want_stats))[1])
     out = net.net(x.cuda())
     assert sorted(calls) == [(16, 32)] * 6 + [(32, 16)] * 5 + [(64, 8)] * 5
+    assert sorted(downs) == [(16, 32), (32, 16)]
     monkeypatch.setattr(conv, "ENABLED", False)
     calls.clear()
+    downs.clear()
     net.eval()
     ref = net.net(x.cuda())
-    assert not calls
+    assert not calls and not downs
     monkeypatch.setattr(conv, "ENABLED", True)
     torch.testing.assert_close(net.net(x.cuda()), ref, rtol=1e-4, atol=1e-4)
     assert out.shape == (4, 10)
@@ -161,3 +167,49 @@ def test_epilogue_statistics_feed_the_batchnorm(c, hw):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError, match="stats"):
         bn.bn_train(y, gamma, beta, None, None, 0.1, 1e-5, None, True, stats.float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,hwi", sorted(conv.DOWN_SHAPES))
+@pytest.mark.parametrize("n", [128, 7, 1])
+def test_down_block_pair_matches_float64_reference(cin, hwi, n):
+    "3x3/stride 2 + 1x1/stride 2 on the same input as one operator: outputs, statistics, all three gradients"
+    g = torch.Generator().manual_seed(100 * cin + n)
+    x = torch.randn(n, cin, hwi, hwi, generator=g).cuda()
+    wm = (torch.randn(2 * cin, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** .5).cuda()
+    ws = (torch.randn(2 * cin, cin, 1, 1, generator=g) * (2.0 / cin) ** .5).cuda()
+    dym = torch.randn(n, 2 * cin, hwi // 2, hwi // 2, generator=g).cuda()
+    dys = torch.randn(n, 2 * cin, hwi // 2, hwi // 2, generator=g).cuda()
+    assert conv.down_supported(x, wm, ws) and not conv.down_supported(x.cpu(), wm.cpu(), ws.cpu())
+    assert not conv.down_supported(x, wm, ws.reshape(2 * cin, cin))
+
+    xd, wmd, wsd = (t.double().requires_grad_() for t in (x, wm, ws))
+    rm, rs = F.conv2d(xd, wmd, stride=2, padding=1), F.conv2d(xd, wsd, stride=2)
+    ((rm * dym.double()).sum() + (rs * dys.double()).sum()).backward()
+
+    xg, wmg, wsg = (t.clone().requires_grad_() for t in (x, wm, ws))
+    ym, ys, sm, ss = conv.conv_down(xg, wmg, wsg, True)
+    ((ym * dym).sum() + (ys * dys).sum()).backward()
+    eps = torch.finfo(torch.float32).eps
+    tol = 64 * eps * (9 * cin) ** .5
+    for got, ref in ((ym, rm), (ys, rs), (xg.grad, xd.grad)):
+        assert (got.double() - ref.detach()).abs().max() <= tol * max(1.0, ref.abs().max().item())
+    tol_w = 64 * eps * (n * hwi * hwi / 4) ** .5
+    for got, ref in ((wmg.grad, wmd.grad), (wsg.grad, wsd.grad)):
+        assert (got.double() - ref).abs().max() <= tol_w * max(1.0, ref.abs().max().item())
+    for st, ref in ((sm, rm), (ss, rs)):
+        assert st.shape == (2 * cin, n * (hwi // 16), 2)
+        torch.testing.assert_close(st[:, :, 0].sum(1), ref.detach().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+        torch.testing.assert_close(st[:, :, 1].sum(1), (ref.detach() ** 2).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    # without statistics, and reproducibly
+    x2, wm2, ws2 = (t.clone().requires_grad_() for t in (x, wm, ws))
+    ym2, ys2 = conv.conv_down(x2, wm2, ws2)
+    ((ym2 * dym).sum() + (ys2 * dys).sum()).backward()
+    assert torch.equal(ym2, ym) and torch.equal(ys2, ys)
+    for a, b in ((x2, xg), (wm2, wmg), (ws2, wsg)):
+        assert torch.equal(a.grad, b.grad)
+    # accumulating into existing gradients takes the immediate-reduction route: same bits
+    ym3, ys3 = conv.conv_down(x2, wm2, ws2)
+    ((ym3 * dym).sum() + (ys3 * dys).sum()).backward()
+    assert torch.equal(wm2.grad, wmg.grad + wmg.grad) and torch.equal(ws2.grad, wsg.grad + wsg.grad)
+    assert not conv._pending
