@@ -167,6 +167,10 @@ EXPORTS = {
     "sgmcmc_conv_down_scratch_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_conv_down_bwd": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 3
                              + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv_stem_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv_stem_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv_stem_wrw": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                                     ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -207,3 +207,60 @@ def conv_down(x, w_main, w_short, want_stats=False):
     (channels, side) pairs in DOWN_SHAPES; with ``want_stats`` also the two outputs' batch statistics
     (see ``conv3x3``)."""
     return _ConvDown.apply(x, w_main, w_short, want_stats)
+
+
+# ------------------------------------------------------------------ the stem
+def stem_supported(x, w, bias, stride, padding, dilation, groups):
+    "3 -> 16 channels, 3x3 / stride 1 / pad 1 on 32x32 images that take no gradient (csrc/conv_down_hip.inc)"
+    return (ENABLED and bias is None and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+            and tuple(x.shape[1:]) == (3, 32, 32) and x.shape[0] > 0 and tuple(w.shape) == (16, 3, 3, 3)
+            and w.dtype == torch.float32 and groups == 1 and _pair(stride) == (1, 1)
+            and _pair(padding) == (1, 1) and _pair(dilation) == (1, 1))
+
+
+class _ConvStem(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        lib = _hip.lib()
+        x, w = x.contiguous(), w.contiguous()
+        n = x.shape[0]
+        y = torch.empty((n, 16, 32, 32), dtype=torch.float32, device=x.device)
+        stats = torch.empty((16, 4 * n, 2), dtype=torch.float64, device=x.device) if want_stats else None
+        err = lib.sgmcmc_conv_stem_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                                       0 if stats is None else stats.data_ptr(), n, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_stem_fwd")
+        ctx.save_for_backward(x, w)
+        if not want_stats:
+            return y
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, *_):
+        lib = _hip.lib()
+        x, w = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        dy = dy.contiguous()
+        n = x.shape[0]
+        scratch = torch.empty(lib.sgmcmc_conv_stem_scratch_floats(n), dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv_stem_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n,
+                                       ctypes.byref(slabs) if defer else None, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_stem_wrw")
+        if defer:
+            _pending.append((scratch, dw, slabs.value))
+            return None, dw.view(dw.shape), None
+        return None, dw, None
+
+
+def conv_stem(x, w, want_stats=False):
+    "conv2d(x, w, padding=1) for x [N, 3, 32, 32] (no gradient), w [16, 3, 3, 3]; see ``conv3x3``"
+    return _ConvStem.apply(x, w, want_stats)

@@ -61,6 +61,8 @@ class Conv2d(_PriorBacked):
         w, b = self.weight, self.bias
         if _conv.supported(x, w, b, *self.conv_args):      # the trunk's 3x3s: fp32-MFMA kernels
             return _conv.conv3x3(x, w, want_stats)
+        if _conv.stem_supported(x, w, b, *self.conv_args):
+            return _conv.conv_stem(x, w, want_stats)
         y = nn.functional.conv2d(x, w, b, *self.conv_args)
         return (y, None) if want_stats else y
 

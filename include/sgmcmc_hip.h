@@ -367,6 +367,14 @@ int sgmcmc_conv_down_bwd(const float* x, const float* w_main, const float* w_sho
                          const float* dy_short, float* dx, float* dw_main, float* dw_short, float* scratch,
                          int n_img, int cin, int hwi, int* deferred_slabs, void* stream);
 
+/* The stem convolution, 3 -> 16 channels, 3x3 / stride 1 / pad 1 on 32x32 images (google_resnet.py:96-100):
+ * forward (+ optional per-band statistics [16][4 n_img][2]) and weight gradient (the images take no
+ * gradient); scratch / deferred_slabs as for sgmcmc_conv3x3_bwd. */
+int sgmcmc_conv_stem_fwd(const float* x, const float* w, float* y, double* stats, int n_img, void* stream);
+int64_t sgmcmc_conv_stem_scratch_floats(int n_img);
+int sgmcmc_conv_stem_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
+                         int* deferred_slabs, void* stream);
+
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
  * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):

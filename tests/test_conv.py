@@ -213,3 +213,32 @@ def test_down_block_pair_matches_float64_reference(cin, hwi, n):
     ((ym3 * dym).sum() + (ys3 * dys).sum()).backward()
     assert torch.equal(wm2.grad, wmg.grad + wmg.grad) and torch.equal(ws2.grad, wsg.grad + wsg.grad)
     assert not conv._pending
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 3, 1])
+def test_stem_convolution_matches_float64_reference(n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 3, 32, 32, generator=g).cuda()
+    w = (torch.randn(16, 3, 3, 3, generator=g) * (2.0 / 27) ** .5).cuda()
+    dy = torch.randn(n, 16, 32, 32, generator=g).cuda()
+    assert conv.stem_supported(x, w, None, 1, 1, 1, 1) and not conv.stem_supported(x, w, None, 2, 1, 1, 1)
+    assert not conv.stem_supported(x.clone().requires_grad_(), w, None, 1, 1, 1, 1)
+    wd = w.double().requires_grad_()
+    ref = F.conv2d(x.double(), wd, padding=1)
+    (ref * dy.double()).sum().backward()
+    wg = w.clone().requires_grad_()
+    y, st = conv.conv_stem(x, wg, True)
+    (y * dy).sum().backward()
+    eps = torch.finfo(torch.float32).eps
+    assert (y.double() - ref.detach()).abs().max() <= 64 * eps * 27 ** .5 * max(1.0, ref.abs().max().item())
+    assert (wg.grad.double() - wd.grad).abs().max() <= 64 * eps * (n * 1024) ** .5 * max(1.0, wd.grad.abs().max().item())
+    assert st.shape == (16, 4 * n, 2)
+    torch.testing.assert_close(st[:, :, 0].sum(1), ref.detach().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(st[:, :, 1].sum(1), (ref.detach() ** 2).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    w2 = w.clone().requires_grad_()
+    y2 = conv.conv_stem(x, w2)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y2, y) and torch.equal(w2.grad, wg.grad)
+    (conv.conv_stem(x, w2) * dy).sum().backward()          # accumulation: immediate reduction, same bits
+    assert torch.equal(w2.grad, wg.grad + wg.grad) and not conv._pending
