@@ -108,6 +108,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, want_stats):
         x, w = x.contiguous(), w.contiguous()
         ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)     # no zero tensors for the (non-differentiable) statistics output
         y, stats = _run(x, w, False, want_stats)
         if not want_stats:
             return y
@@ -118,6 +119,8 @@ class _Conv3x3(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
+        if dy is None:                 # the output took no gradient (grads are not materialised here)
+            return None, None, None
         dy = dy.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             defer = DEFER_REDUCE and w.is_leaf and w.grad is None
@@ -169,6 +172,7 @@ class _ConvDown(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv_down_fwd")
         ctx.save_for_backward(x, w_main, w_short)
+        ctx.set_materialize_grads(False)
         if not want_stats:
             return ym, ys
         ctx.mark_non_differentiable(sm, ss)
@@ -179,7 +183,12 @@ class _ConvDown(torch.autograd.Function):
     def backward(ctx, dym, dys, *_):
         lib = _hip.lib()
         x, w_main, w_short = ctx.saved_tensors
-        dym, dys = dym.contiguous(), dys.contiguous()
+        if dym is None and dys is None:
+            return None, None, None, None
+        n_, c_, hw_ = x.shape[0], x.shape[1], x.shape[2]
+        zeros = lambda: torch.zeros((n_, 2 * c_, hw_ // 2, hw_ // 2), dtype=torch.float32, device=x.device)
+        dym = zeros() if dym is None else dym.contiguous()
+        dys = zeros() if dys is None else dys.contiguous()
         n, c, hw = x.shape[0], x.shape[1], x.shape[2]
         scratch = torch.empty(lib.sgmcmc_conv_down_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
@@ -231,6 +240,7 @@ class _ConvStem(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv_stem_fwd")
         ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)     # no zero tensors for the (non-differentiable) statistics output
         if not want_stats:
             return y
         ctx.mark_non_differentiable(stats)
@@ -241,7 +251,7 @@ class _ConvStem(torch.autograd.Function):
     def backward(ctx, dy, *_):
         lib = _hip.lib()
         x, w = ctx.saved_tensors
-        if not ctx.needs_input_grad[1]:
+        if dy is None or not ctx.needs_input_grad[1]:
             return None, None, None
         dy = dy.contiguous()
         n = x.shape[0]
