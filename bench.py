@@ -229,7 +229,7 @@ def main():
         all_b = list(pool.index_batches()) if fused else list(pool)
         opt = runner.optimizer
 
-        def one_sample(step, reject=True):
+        def one_sample(step, reject=runner.reject_samples):
             for i, (x, y) in enumerate(all_b):
                 step += 1
                 runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
