@@ -1116,3 +1116,4 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "conv_hip.inc"
 #include "conv_down_hip.inc"
 #include "bn_hip.inc"
+#include "pool_hip.inc"

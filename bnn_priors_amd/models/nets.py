@@ -18,6 +18,7 @@ from torch import nn
 
 from .. import bn as _bn
 from .. import conv as _conv
+from .. import pool as _pool
 from .. import prior
 from .base import ClassificationModel, RegressionModel
 
@@ -151,7 +152,35 @@ def ClassificationConvNet(in_channels, img_height, out_features, width, depth=3,
     layers.append(nn.Flatten())
     flat = width * (img_height // 2 ** (depth - 1)) ** 2
     layers.append(LinearPrior(flat, out_features, **kw))
-    return ClassificationModel(nn.Sequential(*layers), softmax_temp)
+    return ClassificationModel(_ConvPoolTrunk(*layers), softmax_temp)
+
+
+class _ConvPoolTrunk(nn.Sequential):
+    "a Sequential that runs every Conv2d(+bias) -> ReLU -> MaxPool2d(2) triple as conv + one fused operator"
+
+    def forward(self, x):
+        mods, i = list(self), 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    and _is_pool2(mods[i + 2]) and m.conv_args[3] == 1):
+                y = nn.functional.conv2d(x, m.weight, None, *m.conv_args)      # bias joins the fused tail
+                b = m.bias
+                if _pool.supported(y, b):
+                    x, i = _pool.bias_relu_pool(y, b), i + 3
+                    continue
+                if b is not None:
+                    y = y + b.view(1, -1, 1, 1)
+                x, i = mods[i + 2](nn.functional.relu(y)), i + 3
+            else:
+                x, i = m(x), i + 1
+        return x
+
+
+def _is_pool2(m):
+    return (isinstance(m, nn.MaxPool2d) and m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2))
+            and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) and not m.ceil_mode
+            and not m.return_indices)
 
 
 class _BatchNorm2d(nn.BatchNorm2d):

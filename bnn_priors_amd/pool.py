@@ -1,0 +1,72 @@
+"""``maxpool2x2(relu(x + bias))`` of the convolutional classifier as one HIP operator, forward and
+backward (``csrc/pool_hip.inc``; C ABI ``sgmcmc_bias_relu_pool_fwd/_bwd``): what follows every
+convolution of bnn_priors/models/conv_nets.py:44-56.  The convolution then runs without its bias; the
+bias gradient comes out of the same backward pass (per-block partials, fixed-order reduction).
+"""
+import os
+
+import torch
+
+from . import _hip
+from . import conv as _conv
+
+ENABLED = os.environ.get("SGMCMC_POOL", "1") != "0"
+
+
+def supported(x, bias):
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and (bias is None or (bias.dtype == torch.float32 and bias.shape == (x.shape[1],))))
+
+
+class _BiasReluPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        err = _hip.lib().sgmcmc_bias_relu_pool_fwd(x.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                   y.data_ptr(), n, c, h, w, _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_bias_relu_pool_fwd")
+        ctx.save_for_backward(x, bias)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        import ctypes
+        lib = _hip.lib()
+        x, bias = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        want_b = bias is not None and ctx.needs_input_grad[1]
+        part = db = None
+        if want_b:
+            slices = lib.sgmcmc_pool_slices(n, c, h, w)
+            part = torch.empty((slices, c), dtype=torch.float32, device=x.device)
+            db = torch.empty_like(bias)
+        err = lib.sgmcmc_bias_relu_pool_bwd(x.data_ptr(), 0 if bias is None else bias.data_ptr(), dy.data_ptr(),
+                                            dx.data_ptr(), 0 if part is None else part.data_ptr(), n, c, h, w,
+                                            _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_bias_relu_pool_bwd")
+        if not want_b:
+            return dx, None
+        if _conv.DEFER_REDUCE and bias.is_leaf and bias.grad is None:
+            # summed with the convolutions' weight-gradient slabs at the end of the backward pass
+            torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
+            _conv._pending.append((part, db, part.shape[0]))
+            return dx, db.view(db.shape)
+        job = (_hip.ReduceJob * 1)()
+        job[0].part, job[0].out, job[0].n_slabs, job[0].numel = part.data_ptr(), db.data_ptr(), part.shape[0], c
+        err = lib.sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_wrw_reduce_many")
+        return dx, db
+
+
+def bias_relu_pool(x, bias=None):
+    "max_pool2d(relu(x + bias[None, :, None, None]), 2) for NCHW float32 tensors with even height and width"
+    return _BiasReluPool.apply(x, bias)

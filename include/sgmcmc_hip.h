@@ -396,6 +396,17 @@ int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const f
                         int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,
                         double* scratch, void* stream);
 
+/* y = maxpool2x2(relu(x + bias_c)), NCHW fp32, h and w even: the Conv2d(+bias) -> ReLU -> MaxPool2d(2) tail
+ * of models/conv_nets.py:44-56 in one pass (the convolution itself is then run without its bias).
+ * Backward: dx in full (the gradient goes to the first maximal element of each window, as ATen, if its
+ * pre-activation is positive); dbias_part (may be NULL): [sgmcmc_pool_slices(...)][channels] partial sums
+ * for sgmcmc_wrw_reduce_many.  `bias` may be NULL (= 0). */
+int sgmcmc_pool_slices(int n, int channels, int h, int w);
+int sgmcmc_bias_relu_pool_fwd(const float* x, const float* bias, float* y, int n, int channels, int h, int w,
+                              void* stream);
+int sgmcmc_bias_relu_pool_bwd(const float* x, const float* bias, const float* dy, float* dx,
+                              float* dbias_part, int n, int channels, int h, int w, void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

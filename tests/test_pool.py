@@ -1,0 +1,82 @@
+"""maxpool2x2(relu(x + bias)) as one operator (csrc/pool_hip.inc) against ATen, forward and backward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bnn_priors_amd import pool
+
+
+def test_supported_is_false_on_cpu_and_odd_sizes():
+    assert not pool.supported(torch.zeros(2, 3, 4, 4), None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 50, 28, 28), (128, 50, 14, 14), (5, 3, 6, 10), (1, 1, 2, 2)])
+@pytest.mark.parametrize("with_bias,ties", [(True, False), (False, False), (True, True)])
+def test_matches_aten(shape, with_bias, ties):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    if ties:                      # coarse values: many equal maxima inside a window, many exact zeros
+        x = (x * 2).round() / 2
+    x = x.cuda()
+    b = (torch.randn(shape[1], generator=g).cuda() * (0.5 if not ties else 0.0)) if with_bias else None
+    dy = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g).cuda()
+    assert pool.supported(x, b) and not pool.supported(x[:, :, :-1], b) and not pool.supported(x.double(), b)
+
+    xr = x.clone().requires_grad_()
+    br = b.clone().requires_grad_() if with_bias else None
+    ref = F.max_pool2d(F.relu(xr + br.view(1, -1, 1, 1) if with_bias else xr), 2)
+    ref.backward(dy)
+
+    xg = x.clone().requires_grad_()
+    bg = b.clone().requires_grad_() if with_bias else None
+    y = pool.bias_relu_pool(xg, bg)
+    y.backward(dy)
+    assert torch.equal(y, ref)                       # max(x) + b == max(x + b) exactly
+    assert torch.equal(xg.grad, xr.grad)             # same routing, ties included
+    if with_bias:
+        n_terms = shape[0] * shape[2] * shape[3] / 4
+        torch.testing.assert_close(bg.grad, br.grad, rtol=1e-5, atol=2e-6 * n_terms ** .5)
+        # accumulation (existing .grad): immediate reduction; reproducible
+        g1 = bg.grad.clone()
+        pool.bias_relu_pool(xg, bg).backward(dy)
+        assert torch.equal(bg.grad, g1 + g1)
+
+
+@pytest.mark.gpu
+def test_nan_propagates_like_aten():
+    x = torch.zeros(1, 1, 2, 4, device="cuda")
+    x[0, 0, 1, 1] = float("nan")
+    y = pool.bias_relu_pool(x, torch.ones(1, device="cuda"))
+    ref = F.max_pool2d(F.relu(x + 1), 2)
+    assert torch.isnan(y[0, 0, 0, 0]) and torch.isnan(ref[0, 0, 0, 0]) and y[0, 0, 0, 1] == ref[0, 0, 0, 1] == 1
+
+
+@pytest.mark.gpu
+def test_convnet_takes_the_fused_tail(monkeypatch):
+    from bnn_priors_amd import models
+    calls = []
+    real = pool.bias_relu_pool
+    monkeypatch.setattr(pool, "bias_relu_pool", lambda x, b=None: (calls.append(tuple(x.shape[1:])), real(x, b))[1])
+    torch.manual_seed(0)
+    x = torch.rand(6, 784)
+    y = torch.randint(0, 10, (6,))
+    kw = dict(width=50, depth=3, weight_prior="laplace", weight_loc=0., weight_scale=2 ** .5, bias_prior="gaussian",
+              bias_loc=0., bias_scale=1., batchnorm=True, weight_prior_params={}, bias_prior_params={})
+    net = models.get_model(x, y, "classificationconvnet", **kw).cuda()
+    out = net.net(x.cuda())
+    assert calls == [(50, 28, 28), (50, 14, 14)]
+    monkeypatch.setattr(pool, "ENABLED", False)
+    calls.clear()
+    ref = net.net(x.cuda())
+    assert not calls
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    # gradients through both routes
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(pool, "ENABLED", on)
+        net.zero_grad()
+        F.cross_entropy(net.net(x.cuda()), y.cuda()).backward()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in grads[0]:
+        torch.testing.assert_close(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-5 * max(1.0, grads[1][k].abs().max().item()), msg=k)
