@@ -82,7 +82,7 @@ class _BNTrain(torch.autograd.Function):
 
 
 def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, stats=None):
-    """``stats``: per-slice partial (sum, sum of squares) of x over (N, H, W) per channel, float64
+    """``stats``: per-slice partial (sum, sum of squared deviations from the slice mean) of x over equal parts of (N, H, W) per channel, float64
     [channels][slices][2], if the producer of x already has them (``conv.conv3x3(..., want_stats=True)``);
     the statistics pass over x is skipped then."""
     return _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)

@@ -42,7 +42,7 @@ def _run(x, w, transpose_w, want_stats=False):
     lib = _hip.lib()
     y = torch.empty_like(x)
     stats = None
-    if want_stats:   # [channels][slices][2] partial (sum, sum of squares) of y, for the BatchNorm that follows
+    if want_stats:   # [channels][slices][2] partial (sum, centred sum of squares) of y, for the BatchNorm that follows
         slices = lib.sgmcmc_conv3x3_stat_slices(x.shape[0], x.shape[1], x.shape[2])
         stats = torch.empty((x.shape[1], slices, 2), dtype=torch.float64, device=x.device)
     err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
@@ -134,7 +134,7 @@ class _Conv3x3(torch.autograd.Function):
 
 def conv3x3(x, w, want_stats=False):
     """3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES.
-    ``want_stats``: also return the per-band (sum, sum of squares) of every output channel, float64
+    ``want_stats``: also return the per-band (sum, sum of squared deviations from the band mean) of every output channel, float64
     [channels][slices][2] -- what ``bn.bn_train(..., stats=...)`` needs instead of a pass over y."""
     return _Conv3x3.apply(x, w, want_stats)
 

@@ -318,7 +318,7 @@ int sgmcmc_accumulate_parts(const float* gpart, int n_slices, int64_t stride, do
  *   transpose_w = 1:  y[n,ci,p]  = sum_{co,r,s} x[n,co,p-(r-1,s-1)] w[co,ci,r,s]      (data gradient,
  *                     x = the gradient w.r.t. the forward output)
  *   stats (forward only, may be NULL): [channels][sgmcmc_conv3x3_stat_slices(...)][2] doubles, the
- *   per-band (sum y, sum y^2) of every output channel -- the batch statistics of the BatchNorm that
+ *   per-band (sum y, sum (y - band mean)^2) of every output channel -- the batch statistics of the BatchNorm that
  *   follows, taken from the accumulators (pass them to sgmcmc_bn_train_fwd as stats_in). */
 int sgmcmc_conv3x3_stat_slices(int n_img, int channels, int hw);
 int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int channels, int hw,
@@ -352,8 +352,8 @@ int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stre
  *   y_main[n,co,oy,ox]  = sum_{ci,r,s} x[n,ci,2oy+r-1,2ox+s-1] w_main[co,ci,r,s]     (3x3, stride 2, pad 1)
  *   y_short[n,co,oy,ox] = sum_ci x[n,ci,2oy,2ox] w_short[co,ci]                        (1x1, stride 2)
  * cin -> 2 cin channels, hwi -> hwi/2 pixels, for (cin, hwi) = (16, 32) and (32, 16).  stats_main /
- * stats_short (both or neither): [2 cin][sgmcmc_conv_down_stat_slices(...)][2] per-band (sum, sum of
- * squares) of the two outputs, as for sgmcmc_conv3x3. */
+ * stats_short (both or neither): [2 cin][sgmcmc_conv_down_stat_slices(...)][2] per-band (sum, centred sum
+ * of squares) of the two outputs, as for sgmcmc_conv3x3. */
 int sgmcmc_conv_down_stat_slices(int n_img, int cin, int hwi);
 int sgmcmc_conv_down_fwd(const float* x, const float* w_main, const float* w_short, float* y_main,
                          float* y_short, double* stats_main, double* stats_short, int n_img, int cin,
@@ -384,8 +384,8 @@ int sgmcmc_conv_stem_wrw(const float* x, const float* dy, float* dw, float* scra
  * Backward: dz = dy * (y > 0) when relu;  dresidual (optional) = dz;  dbeta = sum dz;
  *   dgamma = sum dz * xhat;  dx = gamma * invstd * (dz - dbeta/M - xhat * dgamma/M).
  * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane) doubles of per-slice partial sums, combined in
- * a fixed order (deterministic).  Forward: when `stats_in` ([channels][stats_slices][2] partial (sum, sum of
- * squares) of x, e.g. from sgmcmc_conv3x3) is given, the statistics pass over x is skipped. */
+ * a fixed order (deterministic).  Forward: when `stats_in` ([channels][stats_slices][2] partial (sum, sum of squared
+ * deviations from the partial's own mean) of x over EQUAL parts, e.g. from sgmcmc_conv3x3) is given, the statistics pass over x is skipped. */
 int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane);
 int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, double momentum, double eps, int relu,

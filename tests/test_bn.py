@@ -110,3 +110,21 @@ def test_resnet_forward_backward_matches_the_library_path(monkeypatch):
     for k in s0:
         if "running" in k or "num_batches" in k:
             torch.testing.assert_close(s1[k], s0[k], rtol=1e-4, atol=1e-5, msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset", [0.0, 30.0, 3000.0])
+def test_statistics_do_not_cancel_against_the_mean(offset):
+    "a channel whose mean dwarfs its spread: variance and output still match a float64 evaluation"
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(64, 16, 32, 32, generator=g) * 0.25 + offset).cuda()
+    w, b = torch.ones(16, device="cuda"), torch.zeros(16, device="cuda")
+    rm, rv = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
+    y = bn.bn_train(x, w, b, rm, rv, 1.0, 1e-5)                      # momentum 1: running stats = batch stats
+    xd = x.double()
+    var = xd.var(dim=(0, 2, 3), unbiased=True)
+    torch.testing.assert_close(rv.double(), var, rtol=2e-4, atol=0)
+    torch.testing.assert_close(rm.double(), xd.mean(dim=(0, 2, 3)), rtol=1e-6, atol=1e-6)
+    ref = (xd - xd.mean(dim=(0, 2, 3), keepdim=True)) / (xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()
+    # the input itself carries offset * 2^-24 of rounding: that, not the statistics, bounds the agreement
+    torch.testing.assert_close(y.double(), ref, rtol=0, atol=1e-4 + 4 * offset * 2.0 ** -24 / 0.25)

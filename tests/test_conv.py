@@ -9,6 +9,18 @@ from bnn_priors_amd import _hip, conv
 SHAPES = sorted(conv.SHAPES)
 
 
+def _check_stats(stats, ref, parts_per_image):
+    """stats[c][slice] = (sum, sum of squared deviations from the slice's own mean) over equal slices of
+    (N, H, W); ref: float64 [N, C, H, W]"""
+    n, c = ref.shape[0], ref.shape[1]
+    assert stats.shape == (c, n * parts_per_image, 2) and stats.dtype == torch.float64
+    parts = ref.reshape(n, c, parts_per_image, -1).permute(1, 0, 2, 3).reshape(c, n * parts_per_image, -1)
+    scale = max(1.0, ref.abs().max().item())
+    torch.testing.assert_close(stats[:, :, 0], parts.sum(-1), rtol=1e-5, atol=2e-5 * parts.shape[-1] ** .5 * scale)
+    m2 = ((parts - parts.mean(-1, keepdim=True)) ** 2).sum(-1)
+    torch.testing.assert_close(stats[:, :, 1], m2, rtol=1e-4, atol=1e-5 * parts.shape[-1] * scale ** 2)
+
+
 def _data(c, hw, n, seed=0):
     g = torch.Generator().manual_seed(1000 * c + n + seed)
     x = torch.randn(n, c, hw, hw, generator=g)
@@ -151,12 +163,7 @@ def test_epilogue_statistics_feed_the_batchnorm(c, hw):
     x, w, _ = (t.cuda() for t in _data(c, hw, 19))
     y, stats = conv.conv3x3(x, w, want_stats=True)
     assert torch.equal(y, conv.conv3x3(x, w))
-    assert stats.shape == (c, 19 * hw // 8, 2) and stats.dtype == torch.float64
-    yd = y.double()
-    torch.testing.assert_close(stats[:, :, 0].sum(1), yd.sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-4)
-    torch.testing.assert_close(stats[:, :, 1].sum(1), (yd * yd).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-4)
-    band = yd.view(19, c, hw // 8, 8 * hw).sum(-1).permute(1, 0, 2).reshape(c, -1)     # [c][img*bands + band]
-    torch.testing.assert_close(stats[:, :, 0], band, rtol=1e-5, atol=1e-4)
+    _check_stats(stats, y.double(), hw // 8)          # one part per band of 8 rows
     g = torch.Generator().manual_seed(5)
     gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
     outs = []
@@ -198,9 +205,7 @@ def test_down_block_pair_matches_float64_reference(cin, hwi, n):
     for got, ref in ((wmg.grad, wmd.grad), (wsg.grad, wsd.grad)):
         assert (got.double() - ref).abs().max() <= tol_w * max(1.0, ref.abs().max().item())
     for st, ref in ((sm, rm), (ss, rs)):
-        assert st.shape == (2 * cin, n * (hwi // 16), 2)
-        torch.testing.assert_close(st[:, :, 0].sum(1), ref.detach().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
-        torch.testing.assert_close(st[:, :, 1].sum(1), (ref.detach() ** 2).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+        _check_stats(st, ref.detach(), hwi // 16)
     # without statistics, and reproducibly
     x2, wm2, ws2 = (t.clone().requires_grad_() for t in (x, wm, ws))
     ym2, ys2 = conv.conv_down(x2, wm2, ws2)
@@ -233,9 +238,7 @@ def test_stem_convolution_matches_float64_reference(n):
     eps = torch.finfo(torch.float32).eps
     assert (y.double() - ref.detach()).abs().max() <= 64 * eps * 27 ** .5 * max(1.0, ref.abs().max().item())
     assert (wg.grad.double() - wd.grad).abs().max() <= 64 * eps * (n * 1024) ** .5 * max(1.0, wd.grad.abs().max().item())
-    assert st.shape == (16, 4 * n, 2)
-    torch.testing.assert_close(st[:, :, 0].sum(1), ref.detach().sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
-    torch.testing.assert_close(st[:, :, 1].sum(1), (ref.detach() ** 2).sum(dim=(0, 2, 3)), rtol=1e-6, atol=1e-3)
+    _check_stats(st, ref.detach(), 4)
     w2 = w.clone().requires_grad_()
     y2 = conv.conv_stem(x, w2)
     (y2 * dy).sum().backward()
