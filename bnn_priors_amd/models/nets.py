@@ -177,6 +177,11 @@ class _ConvPoolTrunk(nn.Sequential):
         return x
 
 
+def _all_of(kernel, spatial):
+    k = kernel if isinstance(kernel, (tuple, list)) else (kernel, kernel)
+    return tuple(k) == tuple(spatial)
+
+
 def _is_pool2(m):
     return (isinstance(m, nn.MaxPool2d) and m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2))
             and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1)) and not m.ceil_mode
@@ -231,6 +236,12 @@ class _BNTrunk(nn.Sequential):
                 out, i = _conv_bn(m, mods[i + 1], out, relu=True), i + 3     # conv, BN + ReLU
             elif isinstance(m, _BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 out, i = m.fused(out, relu=True), i + 2          # BN + ReLU in one operator
+            elif (isinstance(m, nn.AvgPool2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.Flatten)
+                  and isinstance(mods[i + 2], Linear) and out.dim() == 4
+                  and _all_of(m.kernel_size, out.shape[2:]) and m.padding in (0, (0, 0))
+                  and _pool.head_supported(out, mods[i + 2].weight, mods[i + 2].bias)):
+                lin = mods[i + 2]                                 # global average pool + linear head
+                out, i = _pool.pool_linear(out, lin.weight, lin.bias), i + 3
             else:
                 out, i = m(out), i + 1
         if self.training:

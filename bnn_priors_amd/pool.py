@@ -70,3 +70,73 @@ class _BiasReluPool(torch.autograd.Function):
 def bias_relu_pool(x, bias=None):
     "max_pool2d(relu(x + bias[None, :, None, None]), 2) for NCHW float32 tensors with even height and width"
     return _BiasReluPool.apply(x, bias)
+
+
+# ------------------------------------------------------------------ global average pool -> Linear
+def head_supported(h, weight, bias):
+    "AvgPool2d over the whole map -> Flatten -> Linear as one operator (csrc/pool_hip.inc, namespace head)"
+    if not (ENABLED and h.is_cuda and h.dtype == torch.float32 and h.dim() == 4 and h.shape[0] > 0):
+        return False
+    c, plane = h.shape[1], h.shape[2] * h.shape[3]
+    return (c <= 64 and plane % 16 == 0 and weight.dim() == 2 and weight.shape[1] == c and weight.shape[0] <= 16
+            and weight.dtype == torch.float32 and (bias is None or bias.shape == (weight.shape[0],)))
+
+
+def _reduce_rows(slabs, out, defer):
+    "out <- sum over rows of slabs [n][numel]: with the pass's other slabs if nothing reads `out` before"
+    import ctypes
+    if defer:
+        torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
+        _conv._pending.append((slabs, out, slabs.shape[0]))
+        return out.view(out.shape)
+    job = (_hip.ReduceJob * 1)()
+    job[0].part, job[0].out, job[0].n_slabs, job[0].numel = slabs.data_ptr(), out.data_ptr(), slabs.shape[0], out.numel()
+    err = _hip.lib().sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, _conv._stream())
+    if err:
+        _hip.check(err, "sgmcmc_wrw_reduce_many")
+    return out
+
+
+class _PoolLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        h, weight = h.contiguous(), weight.contiguous()
+        n, c, plane, k = h.shape[0], h.shape[1], h.shape[2] * h.shape[3], weight.shape[0]
+        pooled = torch.empty((n, c), dtype=torch.float32, device=h.device)
+        logits = torch.empty((n, k), dtype=torch.float32, device=h.device)
+        err = _hip.lib().sgmcmc_pool_linear_fwd(h.data_ptr(), weight.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                pooled.data_ptr(), logits.data_ptr(), n, c, plane, k, _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_pool_linear_fwd")
+        ctx.save_for_backward(pooled, weight, bias)
+        ctx.h_shape = tuple(h.shape)
+        return logits
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dlogits):
+        pooled, weight, bias = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        n, c, hh, ww = ctx.h_shape
+        k = weight.shape[0]
+        dev = pooled.device
+        dh = torch.empty(ctx.h_shape, dtype=torch.float32, device=dev)
+        want_w, want_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        sw = torch.empty((n, k * c), dtype=torch.float32, device=dev) if want_w else None
+        sb = torch.empty((n, k), dtype=torch.float32, device=dev) if want_b else None
+        err = _hip.lib().sgmcmc_pool_linear_bwd(dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
+                                                0 if sw is None else sw.data_ptr(), 0 if sb is None else sb.data_ptr(),
+                                                n, c, hh * ww, k, _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_pool_linear_bwd")
+        dw = db = None
+        if want_w:
+            dw = _reduce_rows(sw, torch.empty_like(weight), _conv.DEFER_REDUCE and weight.is_leaf and weight.grad is None)
+        if want_b:
+            db = _reduce_rows(sb, torch.empty_like(bias), _conv.DEFER_REDUCE and bias.is_leaf and bias.grad is None)
+        return dh, dw, db
+
+
+def pool_linear(h, weight, bias=None):
+    "linear(h.mean(dim=(2, 3)), weight, bias) for NCHW float32 h with <= 64 channels and <= 16 outputs"
+    return _PoolLinear.apply(h, weight, bias)

@@ -407,6 +407,17 @@ int sgmcmc_bias_relu_pool_fwd(const float* x, const float* bias, float* y, int n
 int sgmcmc_bias_relu_pool_bwd(const float* x, const float* bias, const float* dy, float* dx,
                               float* dbias_part, int n, int channels, int h, int w, void* stream);
 
+/* The ResNet's classifier head (google_resnet.py:103-110: AvgPool2d over the whole map -> Flatten -> Linear):
+ *   pooled[n,c] = mean_p h[n,c,p];  logits[n,k] = bias[k] + sum_c weight[k,c] pooled[n,c]
+ * and its gradients: dh[n,c,p] = (sum_k dlogits[n,k] weight[k,c]) / plane; slab_w [n][classes*channels] and
+ * slab_b [n][classes] (either may be NULL) are per-row terms of dweight / dbias for sgmcmc_wrw_reduce_many
+ * (n slabs).  channels <= 64, plane a multiple of 16, classes <= 16; bias may be NULL. */
+int sgmcmc_pool_linear_fwd(const float* h, const float* weight, const float* bias, float* pooled,
+                           float* logits, int n, int channels, int plane, int classes, void* stream);
+int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const float* weight, float* dh,
+                           float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
+                           void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

@@ -80,3 +80,31 @@ def test_convnet_takes_the_fused_tail(monkeypatch):
         grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
     for k in grads[0]:
         torch.testing.assert_close(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-5 * max(1.0, grads[1][k].abs().max().item()), msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,hw,k", [(128, 64, 8, 10), (5, 64, 8, 10), (1, 16, 4, 3), (7, 48, 8, 16)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_pool_linear_head_matches_aten(n, c, hw, k, with_bias):
+    g = torch.Generator().manual_seed(n + c + k)
+    h = torch.randn(n, c, hw, hw, generator=g).cuda()
+    w = (torch.randn(k, c, generator=g) * 0.3).cuda()
+    b = torch.randn(k, generator=g).cuda() if with_bias else None
+    dl = torch.randn(n, k, generator=g).cuda()
+    assert pool.head_supported(h, w, b) and not pool.head_supported(h.cpu(), w.cpu(), None)
+    hd, wd = h.double().requires_grad_(), w.double().requires_grad_()
+    bd = b.double().requires_grad_() if with_bias else None
+    ref = F.linear(hd.mean(dim=(2, 3)), wd, bd)
+    ref.backward(dl.double())
+    hg, wg = h.clone().requires_grad_(), w.clone().requires_grad_()
+    bg = b.clone().requires_grad_() if with_bias else None
+    out = pool.pool_linear(hg, wg, bg)
+    out.backward(dl)
+    torch.testing.assert_close(out.double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(hg.grad.double(), hd.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(wg.grad.double(), wd.grad, rtol=1e-4, atol=1e-5 * n ** .5)
+    if with_bias:
+        torch.testing.assert_close(bg.grad.double(), bd.grad, rtol=1e-4, atol=1e-5 * n ** .5)
+    g1 = wg.grad.clone()                       # accumulation: immediate reduction, same bits
+    pool.pool_linear(hg, wg, bg).backward(dl)
+    assert torch.equal(wg.grad, g1 + g1) and not pool._conv._pending
