@@ -595,17 +595,21 @@ __device__ __forceinline__ void finalize_step_body(const sgmcmc_layout& L, const
 // VerletSGLD.delta_energy for the gradient this transition used, so a metric step needs no
 // further reduction launches.
 __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
-  // wave w owns segments seg_begin + w, + n_waves, ...: its 64 lanes stride over the segment's chunk
-  // partials (all loads independent), then a fixed shuffle tree; lane 0 does the bookkeeping.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)(blockDim.x >> 6);
+  // A group of lanes owns segments seg_begin + g, + n_groups, ...: its lanes stride over the segment's chunk
+  // partials (all loads independent), then a fixed shuffle tree; the group's first lane does the
+  // bookkeeping.  Every segment is a chain of dependent loads, so the number of ROUNDS is what costs:
+  // whole waves while there are enough of them, 16-lane groups (4 segments per wave) for many-tensor nets.
+  const int n_segs = A.seg_end - A.seg_begin;
+  const int gsz = n_segs * 64 <= (int)blockDim.x ? 64 : 16;
+  const int lane = threadIdx.x & (gsz - 1), grp = threadIdx.x / gsz, n_grp = (int)blockDim.x / gsz;
   const bool with_lp = (A.flags & SGMCMC_WITH_LOG_PRIOR) && (A.flags & SGMCMC_CALC_METRICS);
   constexpr int kSmallSegs = 256;
   __shared__ double seg_e[kSmallSegs], seg_lp[kSmallSegs];  // each segment's energy term / log-prior
-  for (int seg = A.seg_begin + wave; seg < A.seg_end; seg += n_waves) {
+  for (int seg = A.seg_begin + grp; seg < A.seg_end; seg += n_grp) {
     const sgmcmc_segment s = L.segs[seg];
     const int64_t n = seg_chunks(L, s);
     double S[SGMCMC_NSUMS + 1] = {0, 0, 0, 0, 0, 0, 0};
-    for (int64_t c = lane; c < n; c += 64) {
+    for (int64_t c = lane; c < n; c += gsz) {
       const double* __restrict__ q = L.partials + (s.first_chunk + c) * SGMCMC_PSTRIDE;
 #pragma unroll
       for (int k = 0; k < SGMCMC_NSUMS + 1; ++k) S[k] += q[k];
@@ -613,8 +617,7 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
 #pragma unroll
     for (int k = 0; k < SGMCMC_NSUMS + 1; ++k) {
       double x = S[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      for (int off = gsz >> 1; off > 0; off >>= 1) x += __shfl_down(x, off, gsz);
       S[k] = x;
     }
     if (lane == 0) {
