@@ -1120,3 +1120,4 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "conv_down_hip.inc"
 #include "bn_hip.inc"
 #include "pool_hip.inc"
+#include "augment_hip.inc"

@@ -66,8 +66,13 @@ class _BatchSource:
                      and type(dataloader.sampler) in samplers
                      and dataloader.batch_size is not None and dataloader.num_workers == 0
                      and dataloader.collate_fn is torch.utils.data.default_collate)
+        # a data set that augments on read (augment.AugmentedTensorDataset): whole minibatches are gathered
+        # and augmented by one kernel launch, with a fresh draw counter per traversal
+        self.augment = getattr(ds, "augment", None) if self.fast else None
         if self.fast:
             self.x, self.y = (t.to(device) for t in ds.tensors)
+            if self.augment is not None:
+                self.x = self.x.contiguous()
 
     def __len__(self):
         return len(self.dl)
@@ -116,6 +121,15 @@ class _BatchSource:
         torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
         perm, gen = self._permutation()
         stop = n - n % bs if self.dl.drop_last else n
+        if self.augment is not None:
+            draw = self.dl.dataset.next_draw()
+            order = perm if perm is not None else torch.arange(n)
+            order = order.to(self.device)
+            for i in range(0, stop, bs):
+                idx = order[i:i + bs]
+                yield self.augment.gather(self.x, idx, draw), self.y.index_select(0, idx)
+            self._exhausted(gen)
+            return
         if by_index:
             from .fused_dense import IndexBatch
             host = (perm if perm is not None else torch.arange(n)).numpy()

@@ -418,6 +418,17 @@ int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const floa
                            float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
                            void* stream);
 
+/* Minibatch gather from an HBM-resident image set with random crop (zero padding `pad`) and horizontal flip
+ * applied on the way -- the `cifar10_augmented` pipeline (data/CIFAR/cifar.py:136-172: RandomCrop(32,
+ * padding=4), RandomHorizontalFlip) without leaving the device:
+ *   out[b,c,y,x] = data[idx[b], c, y + dy - pad, x' + dx - pad] (0 outside), x' = flip_b ? W-1-x : x,
+ *   (dx, dy, flip_b) = Philox4x32-10(seed; counter (idx[b], draw, purpose 3, stream)) -> r0 % (2 pad + 1),
+ *   r1 % (2 pad + 1), r2 & 1 (only if `flip`).  `idx`: int64 device array of data-set rows; `draw`: the
+ *   caller's per-pass counter.  pad = 0 and flip = 0 is a plain gather. */
+int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, int batch, int channels,
+                          int height, int width, int pad, int flip, uint64_t seed, uint32_t stream,
+                          uint64_t draw, void* stream_);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

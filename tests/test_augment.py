@@ -1,0 +1,108 @@
+"""On-device random crop + flip (csrc/augment_hip.inc) against its numpy restatement (oracle/augment.py):
+bit for bit; plus the properties that stand in for the reference's torchvision stream (uniform offsets,
+fair flips), and the runners' batch source using it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as ref
+from bnn_priors_amd import augment
+
+
+def test_oracle_properties():
+    rows = np.arange(20000)
+    dx, dy, fl = ref.decisions(rows, seed=99, stream=3, draw=5, pad=4, flip=True)
+    assert dx.min() == -4 and dx.max() == 4 and dy.min() == -4 and dy.max() == 4
+    counts = np.bincount((dx + 4) * 9 + (dy + 4), minlength=81)
+    assert counts.min() > 0.75 * 20000 / 81 and counts.max() < 1.25 * 20000 / 81      # uniform over the 81 offsets
+    assert abs(fl.mean() - 0.5) < 0.02
+    assert not np.array_equal(dx, ref.decisions(rows, 99, 3, 6, 4, True)[0])           # a new pass, new crops
+    assert not np.array_equal(dx, ref.decisions(rows, 99, 4, 5, 4, True)[0])           # another chain
+    assert np.array_equal(dx, ref.decisions(rows, 99, 3, 5, 4, True)[0])               # reproducible
+    assert not ref.decisions(rows, 99, 3, 5, 4, False)[2].any()
+    data = np.arange(2 * 3 * 4 * 6, dtype=np.float32).reshape(2, 3, 4, 6)
+    assert np.array_equal(ref.gather(data, [1, 0, 1], 1, 0, 0, pad=0, flip=False), data[[1, 0, 1]])
+    # a flip without a shift is a mirror image; zeros enter where the crop leaves the image
+    rows = np.arange(64) % 2
+    out = ref.gather(data, rows, 7, 0, 0, pad=0, flip=True)
+    _, _, fl = ref.decisions(rows, 7, 0, 0, 0, True)
+    for b in range(64):
+        assert np.array_equal(out[b], data[rows[b]][:, :, ::-1] if fl[b] else data[rows[b]])
+    out = ref.gather(data + 1, np.zeros(200, dtype=int), 7, 0, 0, pad=3, flip=False)
+    dx, dy, _ = ref.decisions(np.zeros(200, dtype=int), 7, 0, 0, 3, False)
+    assert np.array_equal((out == 0).any(axis=(1, 2, 3)), (dx != 0) | (dy != 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pad,flip", [((500, 3, 32, 32), 4, True), ((64, 1, 28, 28), 2, False),
+                                            ((9, 5, 6, 10), 0, True), ((9, 2, 7, 5), 3, True)])
+def test_kernel_matches_oracle_bit_for_bit(shape, pad, flip):
+    g = torch.Generator().manual_seed(sum(shape))
+    data = torch.randn(shape, generator=g)
+    idx = torch.randint(0, shape[0], (128,), generator=g)
+    aug = augment.RandomCropFlip(pad=pad, flip=flip, seed=0x1234_5678_9ABC, stream=5)
+    for draw in (0, 1, 2 ** 33 + 7):
+        got = aug.gather(data.cuda(), idx.cuda(), draw).cpu().numpy()
+        want = ref.gather(data.numpy(), idx.numpy(), aug.seed, aug.stream, draw, pad, flip)
+        assert np.array_equal(got, want)
+    assert aug.gather(data.cuda(), idx[:0].cuda(), 0).shape == (0,) + shape[1:]
+    with pytest.raises(ValueError):
+        aug.gather(data, idx, 0)                      # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_batch_source_augments_every_traversal_anew():
+    from bnn_priors_amd.inference import _BatchSource
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(40, 3, 8, 8, generator=g).cuda(), torch.randint(0, 10, (40,), generator=g).cuda()
+    ds = augment.AugmentedTensorDataset(x, y, augment.RandomCropFlip(pad=2, flip=True, seed=11, stream=1))
+    dl = torch.utils.data.DataLoader(ds, batch_size=16, shuffle=False)
+    src = _BatchSource(dl, torch.device("cuda:0"))
+    assert src.fast and src.augment is ds.augment
+    passes = []
+    for _ in range(2):
+        xs, ys = zip(*list(src))
+        assert [len(b) for b in xs] == [16, 16, 8] and torch.equal(torch.cat(ys), y)
+        passes.append(torch.cat(xs))
+    assert ds.draw == 2 and not torch.equal(passes[0], passes[1])
+    want = ref.gather(x.cpu().numpy(), np.arange(40), 11, 1, 2, 2, True)
+    assert np.array_equal(passes[1].cpu().numpy(), want)
+    # item access (a plain DataLoader) uses the current draw
+    xi, yi = ds[7]
+    assert np.array_equal(xi.cpu().numpy(), want[7]) and yi == y[7]
+    # shuffled: same samples, same augmentation per ROW whatever the batch order
+    dl2 = torch.utils.data.DataLoader(ds, batch_size=16, shuffle=True, generator=torch.Generator().manual_seed(3))
+    src2 = _BatchSource(dl2, torch.device("cuda:0"))
+    xs, ys = zip(*list(src2))
+    # (the DataLoader draws its base seed from the same generator before the sampler's permutation)
+    gen = torch.Generator().manual_seed(3)
+    torch.empty((), dtype=torch.int64).random_(generator=gen)
+    perm = torch.randperm(40, generator=gen)
+    want3 = ref.gather(x.cpu().numpy(), perm.numpy(), 11, 1, 3, 2, True)
+    assert np.array_equal(torch.cat(xs).cpu().numpy(), want3)
+
+
+@pytest.mark.gpu
+def test_reject_runner_runs_on_an_augmented_set():
+    from bnn_priors_amd import inference_reject, models
+    from bnn_priors_amd.storage import MemoryMetrics
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (64,), generator=g).cuda()
+    ds = augment.AugmentedTensorDataset(x, y, augment.RandomCropFlip(seed=5))
+    train = torch.utils.data.DataLoader(ds, batch_size=16, shuffle=True)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:16], y[:16]), batch_size=16)
+    torch.manual_seed(0)
+    model = models.get_model(x, y, "googleresnet", width=50, depth=3, weight_prior="gaussian", weight_loc=0.,
+                             weight_scale=2 ** .5, bias_prior="gaussian", bias_loc=0., bias_scale=1.,
+                             batchnorm=True, weight_prior_params={}, bias_prior_params={}).cuda()
+    metrics = MemoryMetrics()
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, epochs_per_cycle=2, warmup_epochs=1, sample_epochs=1,
+        learning_rate=1e-3, skip=1, metrics_skip=2, temperature=1.0, momentum=0.98, sampling_decay="cosine", cycles=1,
+        precond_update=1, metrics_saver=metrics, model_saver=None, reject_samples=True, seed=3, chain_id=0, cycle_seed=9)
+    runner.run()
+    assert ds.draw >= 4                      # begin() + 2 epochs + the exact pass, each a new traversal
+    _, loss = metrics.column("loss")
+    assert np.isfinite(loss[~np.isnan(loss)]).all()
+    assert runner.get_samples()["net.module.0.weight_prior.p"].shape[0] == 1
