@@ -131,8 +131,16 @@ def flat_arena_point(log2n, device, iters=20):
     times = [ms for ms, _, _ in opt.engine.stop_kernel_timing()]
     avg_ms = sum(times) / len(times)
     gbs = BYTES_PER_PARAM * n / (avg_ms * 1e-3) / 1e9
-    return dict(elements=n, avg_kernel_ms=round(avg_ms, 4), achieved_gbs=round(gbs, 1),
-                frac_of_peak=round(gbs / HBM_PEAK_GBS, 4), min_kernel_ms=round(min(times), 4))
+    out = dict(bound="hbm", kernel="step_kernel_stream<float, VERLET>" if log2n >= 24 else "step_kernel<float, VERLET, vec>",
+               achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+               traffic=None, algorithmic_bytes_per_launch=BYTES_PER_PARAM * n, elements=n,
+               avg_kernel_ms=round(avg_ms, 4), min_kernel_ms=round(min(times), 4), launches=len(times))
+    if log2n == 28:
+        # HBM bytes per launch from the PMC counters, collected by separate rocprofv3 --pmc passes of this same
+        # launch (FETCH_SIZE x2 for gfx950's wide coalesced reads + WRITE_SIZE): not re-measured in this run
+        out["traffic"] = 7.53e9
+        out["traffic_source"] = "profiles/r01_flat_arena_2p28_pmc_{FETCH,WRITE}_SIZE.txt (ratio to algorithmic 1.002)"
+    return out
 
 
 def main():
