@@ -215,9 +215,9 @@ class GraphedAccumulate:
 
         g += grad[ -sum_i log p(y_i | x_i) / N ]     loss += -sum_i log p(y_i | x_i) / N
 
-    captured once on static inputs and replayed per full-size batch: autograd accumulates into
-    the SAME gradient tensors on every replay (``p.grad`` bound to ``self.grads``), the loss into a
-    float64 device scalar.  An epoch-long pass is then L graph launches and no host read-back;
+    captured once on static inputs and replayed per full-size batch: each batch's gradient is added to
+    the SAME accumulator tensors (``self.grads``) by one multi-tensor add, the loss into a float64
+    device scalar.  An epoch-long pass is then L graph launches and no host read-back;
     off-shape batches (the ragged last one) run the same ops eagerly into the same accumulators.
     BatchNorm nets update their running statistics on every replay exactly as the eager pass does;
     the capture's warm-up runs are undone from a snapshot of the model's buffers."""
@@ -250,18 +250,31 @@ class GraphedAccumulate:
                 v.copy_(buffers[k])
         torch.cuda.synchronize(dev)
 
-    def _body(self):
-        this = F.cross_entropy(self.pot._logits(self.x), self.y, reduction="sum") / self.pot.N
+    def _accumulate(self, x, y):
+        # every batch's gradient lands in FRESH tensors (autograd adopts them: no per-tensor `grad += ...`
+        # launches, and the convolution slabs take their one deferred reduction), then ONE multi-tensor add
+        # folds them into the accumulators
+        params = self.eng.params
+        for p in params:
+            p.grad = None
+        this = F.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
         this.backward()
+        torch._foreach_add_(self.grads, [p.grad for p in params])
         self.loss += this.detach().double()
+
+    def _body(self):
+        self._accumulate(self.x, self.y)
 
     def matches(self, x, y):
         return (tuple(x.shape), tuple(y.shape)) == self.shape
 
     def begin(self):
-        "zero the accumulators and make them the parameters' gradients"
+        "zero the accumulators"
         torch._foreach_zero_(self.grads)
         self.loss.zero_()
+
+    def finish(self):
+        "the accumulated full-data gradient becomes the parameters' gradient"
         for p, g in zip(self.eng.params, self.grads):
             p.grad = g
 
@@ -272,6 +285,4 @@ class GraphedAccumulate:
 
     def add_eager(self, x, y):
         "same accumulation without the graph (any batch shape)"
-        this = F.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
-        this.backward()
-        self.loss += this.detach().double()
+        self._accumulate(x, y)

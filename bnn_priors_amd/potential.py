@@ -104,6 +104,7 @@ class Potential:
                 this.backward()
                 loss = loss + this.detach().double()
         if acc is not None:
+            acc.finish()
             loss = acc.loss.clone()
         extra = self._leftover_log_prior()
         if extra is not None:
