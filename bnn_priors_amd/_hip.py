@@ -178,6 +178,10 @@ EXPORTS = {
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
+    "sgmcmc_conv_first_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv_first_wrw": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                                      ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -274,3 +274,54 @@ class _ConvStem(torch.autograd.Function):
 def conv_stem(x, w, want_stats=False):
     "conv2d(x, w, padding=1) for x [N, 3, 32, 32] (no gradient), w [16, 3, 3, 3]; see ``conv3x3``"
     return _ConvStem.apply(x, w, want_stats)
+
+
+# ------------------------------------------------------------------ the convolutional classifier's first layer
+def first_supported(x, w, bias, stride, padding, dilation, groups):
+    "1 -> 50 channels, 3x3 / stride 1 / pad 1 on 28x28 images that take no gradient (namespace convfirst)"
+    return (ENABLED and bias is None and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+            and x.dim() == 4 and tuple(x.shape[1:]) == (1, 28, 28) and x.shape[0] > 0
+            and tuple(w.shape) == (50, 1, 3, 3) and w.dtype == torch.float32 and groups == 1
+            and _pair(stride) == (1, 1) and _pair(padding) == (1, 1) and _pair(dilation) == (1, 1))
+
+
+class _ConvFirst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = x.contiguous(), w.contiguous()
+        n = x.shape[0]
+        y = torch.empty((n, 50, 28, 28), dtype=torch.float32, device=x.device)
+        err = _hip.lib().sgmcmc_conv_first_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_first_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = _hip.lib()
+        x, w = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        dy = dy.contiguous()
+        n = x.shape[0]
+        scratch = torch.empty(lib.sgmcmc_conv_first_scratch_floats(n), dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv_first_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n,
+                                        ctypes.byref(slabs) if defer else None, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_first_wrw")
+        if defer:
+            _pending.append((scratch, dw, slabs.value))
+            return None, dw.view(dw.shape)
+        return None, dw
+
+
+def conv_first(x, w):
+    "conv2d(x, w, padding=1) for x [N, 1, 28, 28] (no gradient), w [50, 1, 3, 3]"
+    return _ConvFirst.apply(x, w)

@@ -164,7 +164,11 @@ class _ConvPoolTrunk(nn.Sequential):
             m = mods[i]
             if (isinstance(m, Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                     and _is_pool2(mods[i + 2]) and m.conv_args[3] == 1):
-                y = nn.functional.conv2d(x, m.weight, None, *m.conv_args)      # bias joins the fused tail
+                w = m.weight                                                    # bias joins the fused tail
+                if _conv.first_supported(x, w, None, *m.conv_args):
+                    y = _conv.conv_first(x, w)
+                else:
+                    y = nn.functional.conv2d(x, w, None, *m.conv_args)
                 b = m.bias
                 if _pool.supported(y, b):
                     x, i = _pool.bias_relu_pool(y, b), i + 3

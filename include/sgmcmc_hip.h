@@ -375,6 +375,14 @@ int64_t sgmcmc_conv_stem_scratch_floats(int n_img);
 int sgmcmc_conv_stem_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                          int* deferred_slabs, void* stream);
 
+/* The convolutional classifier's first layer (models/conv_nets.py:44-51): 1 -> 50 channels, 3x3 / stride 1 /
+ * pad 1 on 28x28 images, without its bias (see sgmcmc_bias_relu_pool_*): forward and weight gradient
+ * (n_img slabs of 450 floats; scratch / deferred_slabs as for sgmcmc_conv3x3_bwd). */
+int sgmcmc_conv_first_fwd(const float* x, const float* w, float* y, int n_img, void* stream);
+int64_t sgmcmc_conv_first_scratch_floats(int n_img);
+int sgmcmc_conv_first_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
+                          int* deferred_slabs, void* stream);
+
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
  * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):

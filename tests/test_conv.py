@@ -245,3 +245,29 @@ def test_stem_convolution_matches_float64_reference(n):
     assert torch.equal(y2, y) and torch.equal(w2.grad, wg.grad)
     (conv.conv_stem(x, w2) * dy).sum().backward()          # accumulation: immediate reduction, same bits
     assert torch.equal(w2.grad, wg.grad + wg.grad) and not conv._pending
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 3, 1])
+def test_first_layer_convolution_matches_float64_reference(n):
+    "1 -> 50 channels on 28x28: 9 taps as three padded k-steps, 50 channels as 3 + 1/8 tiles, ragged pixel tiles"
+    g = torch.Generator().manual_seed(28 + n)
+    x = torch.rand(n, 1, 28, 28, generator=g).cuda()
+    w = (torch.randn(50, 1, 3, 3, generator=g) * (2.0 / 9) ** .5).cuda()
+    dy = torch.randn(n, 50, 28, 28, generator=g).cuda()
+    assert conv.first_supported(x, w, None, 1, 1, 1, 1) and not conv.first_supported(x, w, None, 1, 0, 1, 1)
+    assert not conv.first_supported(x.clone().requires_grad_(), w, None, 1, 1, 1, 1)
+    wd = w.double().requires_grad_()
+    ref = F.conv2d(x.double(), wd, padding=1)
+    ref.backward(dy.double())
+    wg = w.clone().requires_grad_()
+    y = conv.conv_first(x, wg)
+    y.backward(dy)
+    eps = torch.finfo(torch.float32).eps
+    assert (y.double() - ref.detach()).abs().max() <= 32 * eps * max(1.0, ref.abs().max().item())
+    assert (wg.grad.double() - wd.grad).abs().max() <= 64 * eps * (n * 784) ** .5 * max(1.0, wd.grad.abs().max().item())
+    w2 = w.clone().requires_grad_()
+    conv.conv_first(x, w2).backward(dy)
+    assert torch.equal(w2.grad, wg.grad)
+    conv.conv_first(x, w2).backward(dy)
+    assert torch.equal(w2.grad, wg.grad + wg.grad) and not conv._pending
