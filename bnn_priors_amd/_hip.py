@@ -182,6 +182,10 @@ EXPORTS = {
     "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
     "sgmcmc_conv_first_wrw": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                                       ctypes.c_void_p]),
+    "sgmcmc_softmax_xent_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                                        ctypes.c_void_p]),
+    "sgmcmc_softmax_xent_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                                        ctypes.c_void_p]),
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),

@@ -26,6 +26,8 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
+from . import pool as _pool
+
 from . import _hip
 
 
@@ -103,7 +105,7 @@ class GraphedLeapfrog(_ReportSlots):
     def _body(self, capturing, metrics):
         self.opt.zero_grad()
         f = self.pot._logits(self.x)
-        loss = F.cross_entropy(f, self.y)
+        loss = _pool.cross_entropy(f, self.y)
         loss.backward()
         self.eng.refresh(self.opt._preconditioners(), defer_upload=capturing)
         self.eng.prior_grad(self.pot.N, metrics)
@@ -257,7 +259,7 @@ class GraphedAccumulate:
         params = self.eng.params
         for p in params:
             p.grad = None
-        this = F.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
+        this = _pool.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
         this.backward()
         torch._foreach_add_(self.grads, [p.grad for p in params])
         self.loss += this.detach().double()

@@ -140,3 +140,48 @@ class _PoolLinear(torch.autograd.Function):
 def pool_linear(h, weight, bias=None):
     "linear(h.mean(dim=(2, 3)), weight, bias) for NCHW float32 h with <= 64 channels and <= 16 outputs"
     return _PoolLinear.apply(h, weight, bias)
+
+
+# ------------------------------------------------------------------ softmax cross-entropy
+def xent_supported(logits, y):
+    return (ENABLED and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+            and 0 < logits.shape[0] <= 1024 and 0 < logits.shape[1] <= 16 and y.dtype == torch.int64
+            and y.shape == (logits.shape[0],))
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y, scale):
+        logits, y = logits.contiguous(), y.contiguous()
+        b, k = logits.shape
+        probs = torch.empty_like(logits)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        err = _hip.lib().sgmcmc_softmax_xent_fwd(logits.data_ptr(), y.data_ptr(), probs.data_ptr(), loss.data_ptr(),
+                                                 b, k, float(scale), _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_softmax_xent_fwd")
+        ctx.save_for_backward(probs, y)
+        ctx.scale = float(scale)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        probs, y = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(probs)
+        err = _hip.lib().sgmcmc_softmax_xent_bwd(probs.data_ptr(), y.data_ptr(), g.data_ptr(), d.data_ptr(),
+                                                 probs.shape[0], probs.shape[1], ctx.scale, _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_softmax_xent_bwd")
+        return d, None, None
+
+
+def cross_entropy(logits, y, reduction="mean"):
+    """``F.cross_entropy(logits, y, reduction=...)`` ("mean" or "sum") -- one launch each way for float32
+    logits of up to 1024 rows x 16 classes on the GPU, ATen otherwise"""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("reduction must be 'mean' or 'sum'")
+    if xent_supported(logits, y):
+        return _SoftmaxXent.apply(logits, y, 1.0 / logits.shape[0] if reduction == "mean" else 1.0)
+    return torch.nn.functional.cross_entropy(logits, y, reduction=reduction)

@@ -18,6 +18,8 @@ Nothing here synchronises with the host; callers ``.item()`` what they log.
 import torch
 import torch.nn.functional as F
 
+from . import pool as _pool
+
 from .models.base import ClassificationModel
 
 
@@ -53,7 +55,7 @@ class Potential:
             potential.backward()
             return loss, log_prior, potential, accs.mean()
         f = self._logits(x)
-        loss = F.cross_entropy(f, y)
+        loss = _pool.cross_entropy(f, y)
         extra = self._leftover_log_prior()
         (loss if extra is None else loss - extra / self.N).backward()
         self.opt.add_prior_gradient(calc_log_prior=want_metrics)
@@ -100,7 +102,7 @@ class Potential:
             if acc is not None:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:
-                this = F.cross_entropy(self._logits(x), y, reduction="sum") / self.N
+                this = _pool.cross_entropy(self._logits(x), y, reduction="sum") / self.N
                 this.backward()
                 loss = loss + this.detach().double()
         if acc is not None:

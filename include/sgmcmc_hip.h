@@ -437,6 +437,15 @@ int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, int
                           int height, int width, int pad, int flip, uint64_t seed, uint32_t stream,
                           uint64_t draw, void* stream_);
 
+/* loss = scale * sum_b -log softmax(logits_b)[y_b] for up to 1024 rows of up to 16 classes (the likelihood term of
+ * models/base.py:168-191), one launch each way: forward keeps probs [rows][classes] for the backward,
+ * dlogits = *grad_out * scale * (probs - onehot(y)).  scale = 1/rows for the minibatch mean, 1/N in the exact
+ * full-data pass. */
+int sgmcmc_softmax_xent_fwd(const float* logits, const int64_t* y, float* probs, float* loss, int rows,
+                            int classes, double scale, void* stream);
+int sgmcmc_softmax_xent_bwd(const float* probs, const int64_t* y, const float* grad_out, float* dlogits,
+                            int rows, int classes, double scale, void* stream);
+
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,
                          uint64_t draw, uint32_t purpose, void* stream_);

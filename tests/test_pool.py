@@ -108,3 +108,28 @@ def test_pool_linear_head_matches_aten(n, c, hw, k, with_bias):
     g1 = wg.grad.clone()                       # accumulation: immediate reduction, same bits
     pool.pool_linear(hg, wg, bg).backward(dl)
     assert torch.equal(wg.grad, g1 + g1) and not pool._conv._pending
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,k", [(128, 10), (96, 10), (1, 2), (1024, 16), (77, 3)])
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_softmax_cross_entropy_matches_aten(b, k, reduction):
+    g = torch.Generator().manual_seed(b + k)
+    logits = (torch.randn(b, k, generator=g) * 4).cuda()
+    y = torch.randint(0, k, (b,), generator=g).cuda()
+    assert pool.xent_supported(logits, y) and not pool.xent_supported(logits.cpu(), y.cpu())
+    assert not pool.xent_supported(torch.zeros(2000, 10, device="cuda"), torch.zeros(2000, dtype=torch.int64, device="cuda"))
+    ld = logits.double().requires_grad_()
+    ref = F.cross_entropy(ld, y, reduction=reduction)
+    (ref * 0.37).backward()
+    lg = logits.clone().requires_grad_()
+    out = pool.cross_entropy(lg, y, reduction)
+    (out * 0.37).backward()
+    torch.testing.assert_close(out.double(), ref.detach(), rtol=2e-6, atol=1e-6 * (1 if reduction == "mean" else b))
+    torch.testing.assert_close(lg.grad.double(), ld.grad, rtol=1e-5, atol=1e-7)
+    out2 = pool.cross_entropy(logits, y, reduction)
+    assert torch.equal(out2, out.detach())                       # reproducible
+    big = torch.zeros(2000, 10, device="cuda")
+    assert pool.cross_entropy(big, torch.zeros(2000, dtype=torch.int64, device="cuda")).item() == pytest.approx(2.302585, rel=1e-5)
+    with pytest.raises(ValueError):
+        pool.cross_entropy(logits, y, "none")
