@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- leapfrog steps/sec of VerletSGLDReject on the MI355X path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload densenet|convnet|googleresnet]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload googleresnet|convnet|densenet]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,13 +13,30 @@ likelihood AND prior), the fused HIP sampler transition (momentum with friction 
 in-kernel Philox noise, position, RMSprop statistic, the six energy / temperature
 reductions), metric read-back every 10th step, cosine LR schedule.
 
+Default workload: googleresnet on CIFAR-10-shaped batches (BASELINE.json configs[3], the
+north-star target workload; it fits one GPU).  ``--workload densenet`` is configs[1],
+``--workload convnet`` configs[2].
+
+Timed region: after W untimed warm-up steps, BLOCKS of exactly K steps are run back to back
+until at least ``--min-seconds`` (0.5 s) have been timed; the whole region is bracketed by
+barrier + ``torch.cuda.synchronize()`` on both sides and every block boundary carries an event
+on the launch stream.  ``value`` = K / (median block duration), max over ranks; the wall-clock
+rate of the whole region is reported beside it (``wall_steps_per_s``).  With the driver's small
+K the figure therefore does not depend on how long the host needs to fill the launch pipeline.
+
 Chains are independent: rank r runs chain r on GPU r with Philox stream r and its own
-synthetic data (seed 1234 + r); no collective on the data path ("scaling": "weak").
-Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline accounting.
+synthetic data (seed 1234 + r); no collective on the data path ("scaling": "weak").  After the
+timed region a multi-rank run performs the one exchange the path has -- the posterior-predictive
+ensemble over all chains (two small all-reduces over RCCL) and the sample gather -- on synthetic
+tables, checks it against the single-process formula (reference exp_utils.py:300-321) and reports
+its time separately (``exchange``).  Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement".
 """
 import argparse
+import ctypes
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -28,8 +45,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_PARAM = 28    # fp32 intermediate step: read g, m, theta, v + write m, theta, v
+HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), same guide
+BYTES_PER_PARAM = 28       # fp32 intermediate step: read g, m, theta, v + write m, theta, v
 
 WORKLOADS = {
     # name: (model, x shape, N, weight prior)  -- BASELINE.json configs[1], [2], [3]
@@ -42,9 +60,11 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="densenet", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=100, help="K: steps per timed block")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="googleresnet", choices=sorted(WORKLOADS))
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="keep timing blocks of K steps until this long")
+    ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
     ap.add_argument("--sweep-log2", type=int, default=28, help="flat-arena roofline point, log2(elements); 0 = skip")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -52,11 +72,15 @@ def parse():
     ap.add_argument("--cudnn-benchmark", type=int, default=1,
                     help="MIOpen find mode, as the reference sets it (experiments/train_bnn.py:29-31)")
     ap.add_argument("--channels-last", type=int, default=0)
-    ap.add_argument("--samples", type=int, default=3, help="also time K full sample cycles (0 = skip)")
+    ap.add_argument("--samples", type=int, default=10, help="also time K full sample cycles (0 = skip)")
     ap.add_argument("--metrics-skip", type=int, default=10, help="BASELINE configs use 10")
     ap.add_argument("--inference", default="VerletSGLDReject",
                     choices=["VerletSGLDReject", "HMCReject", "SGLDReject"],
                     help="runner, as experiments/train_bnn.py:223-234 names them (headline: VerletSGLDReject)")
+    ap.add_argument("--trajectory", type=int, default=0,
+                    help="HMCReject only: leapfrog steps per trajectory (BASELINE configs[4]: 50); 0 = one epoch")
+    ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
     return ap.parse_args()
 
 
@@ -112,9 +136,86 @@ class _SyntheticSet(torch.utils.data.Dataset):
         return self.n
 
 
+# ------------------------------------------------------------------ live kernel timing
+class PacketTimer:
+    """Durations of single kernels, measured live: ``sgmcmc_time_next_launch`` makes the next launch of
+    the library carry a start / stop event in its dispatch packet, so the elapsed time between the two is
+    the kernel's own execution time on the stream it runs on (what rocprofv3 lists per dispatch)."""
+
+    def __init__(self):
+        from bnn_priors_amd import _hip
+        self._hip, self.lib, self.pairs = _hip, _hip.lib(), []
+
+    def arm(self):
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        self._hip.check(self.lib.sgmcmc_event_create(ctypes.byref(e0)), "event_create")
+        self._hip.check(self.lib.sgmcmc_event_create(ctypes.byref(e1)), "event_create")
+        self._hip.check(self.lib.sgmcmc_time_next_launch(e0, e1), "time_next_launch")
+        self.pairs.append((e0, e1))
+
+    def collect_ms(self):
+        out = []
+        for e0, e1 in self.pairs:
+            ms = ctypes.c_float()
+            self._hip.check(self.lib.sgmcmc_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "event_elapsed")
+            out.append(ms.value)
+            self.lib.sgmcmc_event_destroy(e0)
+            self.lib.sgmcmc_event_destroy(e1)
+        self.pairs = []
+        return out
+
+
+def conv_rooflines(device, n_img=128, iters=60):
+    """The ResNet trunk's convolution kernels against the fp32-MFMA peak: each of the three trunk shapes,
+    forward (``conv3x3_kernel`` + batch statistics) and both gradients (``conv3x3_bwd_kernel``), launched
+    through the C ABI on synthetic tensors with the same shapes as in the step.  Algorithmic flops:
+    2 * N * HW^2 * C^2 * 9 per convolution-shaped contraction (forward: one; backward: two)."""
+    from bnn_priors_amd import _hip
+    lib = _hip.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rows = []
+    for c, hw in ((16, 32), (32, 16), (64, 8)):
+        g = torch.Generator(device=device).manual_seed(c)
+        x = torch.randn((n_img, c, hw, hw), generator=g, device=device)
+        dy = torch.randn((n_img, c, hw, hw), generator=g, device=device)
+        w = torch.randn((c, c, 3, 3), generator=g, device=device) * (2.0 / (9 * c)) ** .5
+        y, dx, dw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+        stats = torch.empty((c, lib.sgmcmc_conv3x3_stat_slices(n_img, c, hw), 2), dtype=torch.float64, device=device)
+        scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n_img, c, hw), device=device)
+        slabs = ctypes.c_int(0)
+        flop1 = 2.0 * n_img * hw * hw * c * c * 9
+
+        def fwd():
+            _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n_img, c, hw, 0,
+                                          stats.data_ptr(), stream), "sgmcmc_conv3x3")
+
+        def bwd():
+            _hip.check(lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                              dw.data_ptr(), scratch.data_ptr(), n_img, c, hw,
+                                              ctypes.byref(slabs), stream), "sgmcmc_conv3x3_bwd")
+        for name, fn, flops in ((f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1),
+                                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(device)
+            t = PacketTimer()
+            for _ in range(iters):
+                t.arm()
+                fn()
+            ms = t.collect_ms()
+            avg = sum(ms) / len(ms)
+            tf = flops / (avg * 1e-3) / 1e12
+            rows.append(dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS,
+                             unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                             algorithmic_flops_per_launch=flops, avg_kernel_us=round(avg * 1e3, 3),
+                             min_kernel_us=round(min(ms) * 1e3, 3), launches=len(ms),
+                             shape=dict(n=n_img, channels=c, hw=hw)))
+    return rows
+
+
 def flat_arena_point(log2n, device, iters=20):
     """The same fused kernel on ONE flat segment of 2^log2n fp32 elements (bandwidth-bound
-    regime): GB/s of algorithmic traffic (28 B/element) from HIP events."""
+    regime): GB/s of algorithmic traffic (28 B/element), kernel durations measured live."""
     from bnn_priors_amd import mcmc
     n = 1 << log2n
     p = torch.nn.Parameter(torch.zeros(n, device=device))
@@ -131,16 +232,80 @@ def flat_arena_point(log2n, device, iters=20):
     times = [ms for ms, _, _ in opt.engine.stop_kernel_timing()]
     avg_ms = sum(times) / len(times)
     gbs = BYTES_PER_PARAM * n / (avg_ms * 1e-3) / 1e9
-    out = dict(bound="hbm", kernel="step_kernel_stream<float, VERLET>" if log2n >= 24 else "step_kernel<float, VERLET, vec>",
-               achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
-               traffic=None, algorithmic_bytes_per_launch=BYTES_PER_PARAM * n, elements=n,
-               avg_kernel_ms=round(avg_ms, 4), min_kernel_ms=round(min(times), 4), launches=len(times))
-    if log2n == 28:
-        # HBM bytes per launch from the PMC counters, collected by separate rocprofv3 --pmc passes of this same
-        # launch (FETCH_SIZE x2 for gfx950's wide coalesced reads + WRITE_SIZE): not re-measured in this run
-        out["traffic"] = 7.53e9
-        out["traffic_source"] = "profiles/r01_flat_arena_2p28_pmc_{FETCH,WRITE}_SIZE.txt (ratio to algorithmic 1.002)"
+    return dict(bound="hbm", kernel="step_kernel_stream<float, VERLET>" if log2n >= 24 else "step_kernel<float, VERLET, vec>",
+                achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                traffic=None, algorithmic_bytes_per_launch=BYTES_PER_PARAM * n, elements=n,
+                avg_kernel_ms=round(avg_ms, 4), min_kernel_ms=round(min(times), 4), launches=len(times))
+
+
+# ------------------------------------------------------------------ the one exchange of the multi-chain path
+def _exchange_tables(rank, E, N, C, device):
+    g = torch.Generator().manual_seed(100 + rank)
+    logits = torch.randn(E, N, C, generator=g, dtype=torch.float64) * 3
+    acc = logits - logits.logsumexp(-1, keepdim=True)
+    y = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(7))
+    lps = acc.gather(-1, y.view(1, N, 1).expand(E, N, 1)).squeeze(-1)
+    return lps.to(device), acc.to(device)
+
+
+def exchange_leg(model, rank, world, device, E, n_test=10000, classes=10):
+    """Posterior-predictive ensemble over ALL chains' samples (two all-reduces, MAX and SUM, over RCCL) and
+    the gather of every chain's stored samples to rank 0, on synthetic [E, N_test, C] tables / E copies of
+    the model's state; the ensemble is checked on rank 0 against the single-process formula applied to the
+    concatenated tables (exp_utils.py:300-321)."""
+    import torch.distributed as dist
+    from bnn_priors_amd.evaluation import ensemble_across_chains, gather_samples
+    lps, acc = _exchange_tables(rank, E, n_test, classes, device)
+    samples = {k: v.detach().unsqueeze(0).repeat((E,) + (1,) * v.dim()) + float(rank)
+               for k, v in model.state_dict().items() if v.is_floating_point()}
+    ensemble_across_chains(lps, acc)                # untimed first use: RCCL sets its rings up lazily
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    lp, ens = ensemble_across_chains(lps, acc)
+    torch.cuda.synchronize(device)
+    t_ens = time.perf_counter() - t0
+    dist.barrier()
+    t0 = time.perf_counter()
+    got = gather_samples(samples)
+    torch.cuda.synchronize(device)
+    t_gather = time.perf_counter() - t0
+    t = torch.tensor([t_ens, t_gather], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = None
+    if rank == 0:
+        parts = [_exchange_tables(r, E, n_test, classes, "cpu") for r in range(world)]
+        all_lps, all_acc = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        ref_lp = all_lps.logsumexp(0) - math.log(all_lps.shape[0])
+        ref_ens = all_acc.logsumexp(0) - math.log(all_acc.shape[0])
+        err = max((lp.cpu() - ref_lp).abs().max().item(), (ens.cpu() - ref_ens).abs().max().item())
+        n_bytes = sum(v.numel() * v.element_size() for v in got.values())
+        ok_gather = all(v.shape[0] == E * world for v in got.values())
+        k0 = sorted(got)[0]
+        ok_gather = ok_gather and all(
+            bool((got[k0][r * E:(r + 1) * E] - samples[k0][0:1]).abs().max().item() == float(r)) for r in range(world))
+        out = dict(backend="nccl (RCCL)", chains=world, samples_per_chain=E, n_test=n_test, classes=classes,
+                   ensemble_ms=round(t[0].item() * 1e3, 3), ensemble_max_abs_err=err,
+                   ensemble_matches_single_process=bool(err < 1e-9),
+                   gather_ms=round(t[1].item() * 1e3, 3), gathered_bytes_rank0=n_bytes,
+                   gather_order_checked=bool(ok_gather),
+                   collectives="all_reduce(MAX) + all_reduce(SUM) on [N_test, C+1] float64; all_gather per stored tensor")
+        if not (out["ensemble_matches_single_process"] and ok_gather):
+            raise AssertionError(f"multi-chain exchange disagrees with the single-process formula: {out}")
     return out
+
+
+def pin_process(local, local_world):
+    "one rank = one contiguous share of the host's CPUs (8 drivers + 8 HIP runtimes must not migrate / collide)"
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // max(1, local_world))
+        mine = cpus[local * per:(local + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(8, len(mine))))
+        return len(mine)
+    except (AttributeError, OSError):
+        return None
 
 
 def main():
@@ -157,8 +322,10 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    pinned_cpus = None
     if distributed:   # one process per GPU under torch.distributed.run; "nccl" is RCCL on ROCm
         import torch.distributed as dist
+        pinned_cpus = pin_process(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         dist.init_process_group("nccl", device_id=device)
 
     from bnn_priors_amd.inference_reject import runner_class
@@ -175,12 +342,15 @@ def main():
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
     hmc = args.inference == "HMCReject"
+    extra = {}
+    if hmc and args.trajectory:
+        extra["trajectory_length"] = args.trajectory
     runner = runner_class(args.inference)(
         model=model, dataloader=loader, dataloader_test=empty_test, epochs_per_cycle=50,
         warmup_epochs=50 if hmc else 45, sample_epochs=0 if hmc else 5, learning_rate=0.01 if not hmc else 1e-4,
-        skip=1, metrics_skip=args.metrics_skip, temperature=1.0, momentum=1.0 if hmc else 0.994,
+        skip=1, metrics_skip=args.metrics_skip, temperature=args.temperature, momentum=1.0 if hmc else 0.994,
         sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
-        model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank)
+        model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank, **extra)
     # the exact initial gradient over the synthetic pool stands in for the full-data pass
     runner._batch_source = pool
     runner.use_graph = not args.eager
@@ -190,36 +360,57 @@ def main():
     batches = list(pool.index_batches()) if fused else list(pool)
     batches = [b for b in batches if len(b[0]) == 128]       # the L-th minibatch is ragged (N % 128)
     path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
-            "eager" if args.eager else "hipGraph of autograd fwd/bwd + fused sampler")
+            "eager" if args.eager else "hipGraph of autograd fwd/bwd (hand-written conv / BN kernels) + fused sampler")
 
     def run(k, step):
         for _ in range(k):
             step += 1
             x, y = batches[step % len(batches)]
             runner.leapfrog(step, x, y, last_of_epoch=False)
-        runner._drain_rows()          # every metric row of these steps has been logged
         return step
 
     step = run(args.warmup, step)
+    runner._drain_rows()
+    stream = torch.cuda.current_stream(device)
+    K = args.steps
+    # how many blocks of K steps make up >= min-seconds: one untimed calibration block, rank 0's clock decides
     torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
     t0 = time.perf_counter()
-    step = run(args.steps, step)
+    step = run(K, step)
+    runner._drain_rows()
+    torch.cuda.synchronize(device)
+    n_blocks = max(1, min(args.max_blocks, math.ceil(args.min_seconds / max(time.perf_counter() - t0, 1e-6))))
+    if distributed:
+        nb = torch.tensor([n_blocks], device=device)
+        dist.broadcast(nb, src=0)
+        n_blocks = int(nb.item())
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    marks = [torch.cuda.Event(enable_timing=True)]
+    marks[0].record(stream)
+    t0 = time.perf_counter()
+    for _ in range(n_blocks):
+        step = run(K, step)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        marks.append(ev)
+    runner._drain_rows()          # every metric row of these steps has been logged
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
+    block_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+    med_ms = statistics.median(block_ms)
     if distributed:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([med_ms, wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        med_ms, wall = t[0].item(), t[1].item()
+    dt_block = med_ms * 1e-3
 
     runner._check_finite()
-    # Live duration of the fused sampler kernel: HIP events cannot bracket a node inside a graph
-    # replay, so the same launches (same arena, same arguments) are issued eagerly right here,
-    # each bracketed by an event pair on its stream.  rocprofv3's per-dispatch durations of the
-    # in-graph launches are in profiles/ and agree.
+    # Live duration of the fused sampler kernel: a node inside a graph replay cannot carry events, so the same
+    # launches (same arena, same arguments) are issued right here, each with a start / stop event in its
+    # dispatch packet.  rocprofv3's per-dispatch durations of the in-graph launches are in profiles/.
     ktimes = []
     if not args.no_kernel_timing:
         opt = runner.optimizer
@@ -250,49 +441,68 @@ def main():
             if reject:
                 opt.maybe_reject(de)
             runner.scheduler.step()
+            if hmc:
+                opt.sample_momentum()
             opt.initial_step(calc_metrics=False, save_state=reject)
             return step
 
-        step = one_sample(step)          # untimed: first use of the ragged last minibatch etc.
-        torch.cuda.synchronize(device)
-        ts = time.perf_counter()
-        for _ in range(args.samples):
-            step = one_sample(step)
-        torch.cuda.synchronize(device)
-        samples = args.samples / (time.perf_counter() - ts)
+        def timed_samples(reject):
+            s = one_sample(step, reject)          # untimed: first use of this variant's launches
+            torch.cuda.synchronize(device)
+            ts = time.perf_counter()
+            for _ in range(args.samples):
+                s = one_sample(s, reject)
+            torch.cuda.synchronize(device)
+            return args.samples / (time.perf_counter() - ts), s
+
+        samples, step = timed_samples(runner.reject_samples)
         # the paper's default, reject_samples=False: no state snapshot at initial_step, no M-H test
         samples_noreject = None
         if runner.reject_samples:
-            ts = time.perf_counter()
-            for _ in range(args.samples):
-                step = one_sample(step, reject=False)
-            torch.cuda.synchronize(device)
-            samples_noreject = args.samples / (time.perf_counter() - ts)
+            samples_noreject, step = timed_samples(False)
+    exchange = exchange_leg(model, rank, world, device, args.exchange_samples) if distributed else None
+
+    value = world * K / dt_block
     out = {
-        "metric": f"leapfrog steps/sec, {args.inference}", "value": round(world * args.steps / dt, 2),
-        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "metric": f"leapfrog steps/sec, {args.inference}", "value": round(value, 2),
+        "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": round(dt_block / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name} {args.inference} batch=128 N={N} (L={L} steps/epoch) "
-                               f"lr=0.01 cosine momentum=0.994 T=1 metrics_skip={args.metrics_skip} prior={prior}",
+                               f"lr={'1e-4' if hmc else '0.01'} cosine momentum={'1' if hmc else '0.994'} "
+                               f"T={args.temperature:g} metrics_skip={args.metrics_skip} prior={prior}"
+                               + (f" trajectory={args.trajectory}" if hmc and args.trajectory else ""),
                    "params": n_params, "tensors": len(list(model.parameters())),
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
                    "step_path": path},
+        "timing": {"blocks": n_blocks, "steps_per_block": K, "timed_steps": n_blocks * K,
+                   "median_block_ms": round(med_ms, 4), "min_block_ms": round(min(block_ms), 4),
+                   "max_block_ms": round(max(block_ms), 4), "region_wall_s": round(wall, 4),
+                   "wall_steps_per_s": round(world * n_blocks * K / wall, 2),
+                   "method": "blocks of K steps back to back, event on the launch stream at every block "
+                             "boundary, region bracketed by barrier + synchronize; value = K / median block "
+                             "(max over ranks)"},
     }
-    if samples is not None:
+    if pinned_cpus is not None:
+        out["config"]["cpus_per_rank"] = pinned_cpus
+    if samples is not None and args.samples >= 10:
         out["samples_per_sec"] = {"value": round(world * samples, 3), "per_chain": round(samples, 3),
+                                  "cycles_timed": args.samples,
                                   "leapfrog_steps_per_sample": L, "reject_samples": runner.reject_samples,
                                   "per_chain_reject_samples_false":
                                       None if samples_noreject is None else round(samples_noreject, 3),
                                   "includes": "L leapfrog steps, exact full-data gradient pass "
                                               "(N rows), final_step, M-H test, initial_step"}
+    if exchange is not None:
+        out["exchange"] = exchange
     if rank == 0:
+        sampler_line = None
         if ktimes:
             chunks = ktimes[0][1]
             avg_ms = sum(t for t, _, _ in ktimes) / len(ktimes)
             algo_bytes = BYTES_PER_PARAM * n_params
             ach = algo_bytes / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {
+            sampler_line = {
                 "bound": "hbm", "kernel": "step_kernel<float, VERLET, vec>",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
@@ -301,6 +511,19 @@ def main():
                 "regime": "launch-latency-bound: the whole sampler state of this net "
                           f"({algo_bytes / 1e6:.2f} MB/launch) is below one launch's fixed cost; "
                           "see roofline_flat_arena for the same kernel in its bandwidth-bound regime"}
+        if args.workload == "googleresnet" and not args.no_kernel_timing:
+            # the step is dominated by the trunk's convolution gradients (profiles/): the headline roofline is
+            # the kernel with the largest share of the step, the sampler's HBM line is reported beside it
+            convs = conv_rooflines(device)
+            share = {r["kernel"]: r["avg_kernel_us"] * (6 if r["shape"]["channels"] == 16 else 5) for r in convs}
+            top = max(convs, key=lambda r: share[r["kernel"]])
+            out["roofline"] = dict(top, share_note="dominant kernel = largest (launches per step x duration) among "
+                                                   "the step's kernels; 5-6 launches per step each")
+            out["roofline_kernels"] = convs
+            if sampler_line:
+                out["roofline_sampler"] = sampler_line
+        elif sampler_line:
+            out["roofline"] = sampler_line
         if args.sweep_log2:
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
         if world == 1 and args.cpu_budget > 0:

@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")]
 SOURCE = SOURCES[0]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CHUNK = 4096
 CHUNK_SMALL = 1024
 NSUMS = 6
@@ -30,7 +30,9 @@ VERLET, HMC, SGLD = 0, 1, 2
 INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM, SMALL_FINALIZE = 1, 2, 4, 8, 16, 32, 64
 WITH_LOG_PRIOR = 128
 DEFER_FINALIZE = 256
-PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T, PRIOR_CAUCHY = 0, 1, 2, 3, 4
+PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T, PRIOR_CAUCHY, PRIOR_GENNORM = 0, 1, 2, 3, 4, 5
+PRIOR_GAMMA_SOFTPLUS, PRIOR_UNIFORM_CDF, PRIOR_HALFCAUCHY_SOFTPLUS = 6, 7, 8
+PRIOR_HAS_LINKS = 1
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
@@ -38,7 +40,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # numpy mirrors of the device-resident tables
 SEGMENT_DTYPE = np.dtype([("theta", "<u8"), ("g", "<u8"), ("M", "<f8"), ("numel", "<i8"),
                           ("first_chunk", "<i8"), ("noise_base", "<i8"), ("prior_kind", "<i4"),
-                          ("reserved", "<i4"), ("prior_loc", "<f8"), ("prior_scale", "<f8"),
+                          ("scale_link", "<i4"), ("prior_loc", "<f8"), ("prior_scale", "<f8"),
                           ("prior_df", "<f8")], align=True)
 CHUNK_DTYPE = np.dtype([("seg", "<i4"), ("n_valid", "<i4")], align=True)
 SEG_STATE_FIELDS = ("sum_gg", "sum_gmo", "sum_gmn", "sum_momo", "sum_mnmn", "sum_thg",
@@ -110,6 +112,8 @@ EXPORTS = {
                                                   ctypes.c_void_p]),
     "sgmcmc_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "sgmcmc_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "sgmcmc_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_time_next_launch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.POINTER(ctypes.c_float)]),
     "sgmcmc_sample_momentum": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.c_double, ctypes.c_double,
@@ -176,7 +180,7 @@ EXPORTS = {
     "sgmcmc_bias_relu_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6
+    "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
     "sgmcmc_conv_first_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),

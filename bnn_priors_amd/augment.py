@@ -20,10 +20,14 @@ __all__ = ("RandomCropFlip", "AugmentedTensorDataset")
 
 
 class RandomCropFlip:
-    def __init__(self, pad=4, flip=True, seed=0, stream=0):
+    def __init__(self, pad=4, flip=True, seed=0, stream=0, fill=None):
+        """``fill``: per-channel value of the padding (sequence of C floats), default 0.  The reference pads
+        the raw image with black BEFORE normalising (cifar.py:158-163), so for a normalised data set pass
+        ``fill = -mean / std`` to reproduce its border exactly."""
         if pad < 0:
             raise ValueError("pad must be >= 0")
         self.pad, self.flip, self.seed, self.stream = int(pad), bool(flip), int(seed), int(stream)
+        self.fill = None if fill is None else torch.as_tensor(fill, dtype=torch.float32).reshape(-1)
 
     def gather(self, data, idx, draw):
         "data [N, C, H, W] float32 on the GPU, idx int64 [B] on the same device -> augmented [B, C, H, W]"
@@ -33,7 +37,14 @@ class RandomCropFlip:
         out = torch.empty((idx.numel(),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
         if idx.numel() == 0:
             return out
-        err = _hip.lib().sgmcmc_augment_gather(data.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(),
+        fill = 0
+        if self.fill is not None:
+            if self.fill.numel() != data.shape[1]:
+                raise ValueError("fill needs one value per channel")
+            if self.fill.device != data.device:
+                self.fill = self.fill.to(data.device)
+            fill = self.fill.data_ptr()
+        err = _hip.lib().sgmcmc_augment_gather(data.data_ptr(), idx.data_ptr(), out.data_ptr(), fill, idx.numel(),
                                                data.shape[1], data.shape[2], data.shape[3], self.pad,
                                                int(self.flip), self.seed & (2 ** 64 - 1), self.stream, int(draw),
                                                torch.cuda.current_stream().cuda_stream)

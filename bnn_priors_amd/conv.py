@@ -16,9 +16,52 @@ import torch
 
 from . import _hip
 
+import contextlib
+
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
 DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
+
+# ---- deferred weight-gradient reduction: opt-in, per backward pass ---------------------------------------
+# Inside ``with deferring():`` (the samplers' own gradient evaluations: potential.py, graphed.py) a
+# convolution's backward hands autograd a weight gradient whose memory is filled by ONE reduction launch at
+# the end of the pass.  That is only sound if AccumulateGrad adopts exactly that tensor and nothing reads it
+# earlier, so a call defers only when ALL of these hold: the context is active, grad mode is off inside
+# backward (no create_graph), the weight is a leaf without a ``.grad`` yet, and the weight took part in ONE
+# forward call of this pass (a weight shared by two operations has its gradients summed mid-backward).
+# Everywhere else -- user code calling these operators directly -- the reduction is launched immediately.
+_defer = {"active": False, "uses": {}}
+
+
+@contextlib.contextmanager
+def deferring():
+    "scope of one forward + backward evaluation whose convolution weight gradients may be reduced at the end"
+    if not DEFER_REDUCE or _defer["active"]:
+        yield
+        return
+    _defer["active"] = True
+    _defer["uses"] = {}
+    _pending.clear()                # leftovers of a pass that raised before its final callback
+    try:
+        yield
+    except BaseException:
+        _pending.clear()
+        raise
+    finally:
+        _defer["active"] = False
+        _defer["uses"] = {}
+    _flush_pending()                # no-op when the backward's final callback already ran
+
+
+def _note_use(*weights):
+    if _defer["active"]:
+        for w in weights:
+            _defer["uses"][id(w)] = _defer["uses"].get(id(w), 0) + 1
+
+
+def _may_defer(*weights):
+    return (_defer["active"] and not torch.is_grad_enabled()
+            and all(w.is_leaf and w.grad is None and _defer["uses"].get(id(w), 0) == 1 for w in weights))
 
 
 def supported(x, w, bias, stride, padding, dilation, groups):
@@ -84,10 +127,7 @@ def _both_grads(x, w, dy, defer):
 
 
 # Weight-gradient slabs whose reduction waits for the end of the running backward pass, where ONE launch
-# sums all of them (autograd's final callback).  Only gradients nothing reads before that point are
-# deferred: leaf weights whose .grad is still None (AccumulateGrad then just keeps the tensor).  A tensor
-# hook that READS a convolution weight's gradient during backward would see it unreduced: set
-# SGMCMC_CONV_DEFER=0 (or conv.DEFER_REDUCE = False) in that case.
+# sums all of them (autograd's final callback); see ``deferring`` above for when a call may defer.
 _pending = []
 
 
@@ -106,6 +146,7 @@ def _flush_pending():
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, want_stats):
+        _note_use(w)
         x, w = x.contiguous(), w.contiguous()
         ctx.save_for_backward(x, w)
         ctx.set_materialize_grads(False)     # no zero tensors for the (non-differentiable) statistics output
@@ -123,7 +164,7 @@ class _Conv3x3(torch.autograd.Function):
             return None, None, None
         dy = dy.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+            defer = _may_defer(w)
             if defer:   # every deferring call queues it; the first one to run does the work
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
             return (*_both_grads(x, w, dy, defer), None)         # one launch for the two of them
@@ -157,6 +198,7 @@ class _ConvDown(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_main, w_short, want_stats):
         lib = _hip.lib()
+        _note_use(w_main, w_short)
         x, w_main, w_short = x.contiguous(), w_main.contiguous(), w_short.contiguous()
         n, c, hw = x.shape[0], x.shape[1], x.shape[2]
         ym = torch.empty((n, 2 * c, hw // 2, hw // 2), dtype=torch.float32, device=x.device)
@@ -193,8 +235,7 @@ class _ConvDown(torch.autograd.Function):
         scratch = torch.empty(lib.sgmcmc_conv_down_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
         dwm, dws = torch.empty_like(w_main), torch.empty_like(w_short)
-        defer = (DEFER_REDUCE and w_main.is_leaf and w_main.grad is None and w_short.is_leaf
-                 and w_short.grad is None)
+        defer = _may_defer(w_main, w_short)
         slabs = ctypes.c_int(0)
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
@@ -231,6 +272,7 @@ class _ConvStem(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, want_stats):
         lib = _hip.lib()
+        _note_use(w)
         x, w = x.contiguous(), w.contiguous()
         n = x.shape[0]
         y = torch.empty((n, 16, 32, 32), dtype=torch.float32, device=x.device)
@@ -257,7 +299,7 @@ class _ConvStem(torch.autograd.Function):
         n = x.shape[0]
         scratch = torch.empty(lib.sgmcmc_conv_stem_scratch_floats(n), dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
-        defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+        defer = _may_defer(w)
         slabs = ctypes.c_int(0)
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
@@ -288,6 +330,7 @@ def first_supported(x, w, bias, stride, padding, dilation, groups):
 class _ConvFirst(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
+        _note_use(w)
         x, w = x.contiguous(), w.contiguous()
         n = x.shape[0]
         y = torch.empty((n, 50, 28, 28), dtype=torch.float32, device=x.device)
@@ -308,7 +351,7 @@ class _ConvFirst(torch.autograd.Function):
         n = x.shape[0]
         scratch = torch.empty(lib.sgmcmc_conv_first_scratch_floats(n), dtype=torch.float32, device=x.device)
         dw = torch.empty_like(w)
-        defer = DEFER_REDUCE and w.is_leaf and w.grad is None
+        defer = _may_defer(w)
         slabs = ctypes.c_int(0)
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)

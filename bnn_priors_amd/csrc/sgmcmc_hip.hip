@@ -20,9 +20,28 @@
 //          the per-segment energy / temperature bookkeeping.  No float atomics anywhere:
 //          results are bitwise run-to-run reproducible and independent of launch timing.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "sgmcmc_hip.h"
+
+// Every kernel launch of this library goes through SGMCMC_LAUNCH.  Normally that is hipLaunchKernelGGL;
+// after sgmcmc_time_next_launch(e0, e1) the NEXT launch carries the two events in its dispatch packet
+// (hipExtLaunchKernelGGL), so hipEventElapsedTime(e0, e1) is that kernel's own execution time -- what
+// rocprofv3 reports per dispatch -- without the ~3 us a pair of hipEventRecord calls adds around it.
+namespace sgmcmc_timing {
+static hipEvent_t e0 = nullptr, e1 = nullptr;
+}
+#define SGMCMC_LAUNCH(kernel, grid, block, lds, stream, ...)                                           \
+  do {                                                                                                 \
+    if (sgmcmc_timing::e0) {                                                                           \
+      hipEvent_t a_ = sgmcmc_timing::e0, b_ = sgmcmc_timing::e1;                                       \
+      sgmcmc_timing::e0 = sgmcmc_timing::e1 = nullptr;                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, a_, b_, 0, __VA_ARGS__);                 \
+    } else {                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                               \
+    }                                                                                                  \
+  } while (0)
 
 // Every entry point reports ITS launches through hipGetLastError().  That state is process-wide and
 // sticky: a failed pointer query inside another library (ATen's pinned-memory checks leave
@@ -274,43 +293,104 @@ struct GradParts {
   double num_data;
 };
 
-__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s);  // defined with the prior kernels
+__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s, double scale);  // defined with the prior kernels
 
-// d/dtheta[-log p(theta)/N] added to g, and (optionally) the un-normalised log-density into lp
+// value x of a hierarchical scale given the raw hyper-parameter s (see SGMCMC_PRIOR_* in the header) and dx/ds
+__device__ __forceinline__ double hyper_value(const sgmcmc_segment& h, double s, double& dxds) {
+  const double sig = 1.0 / (1.0 + exp(-s)), sp = s > 30.0 ? s : log1p(exp(s));
+  if (h.prior_kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) { dxds = sig; return sp; }
+  if (h.prior_kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) { dxds = sig * h.prior_loc; return sp * h.prior_loc; }
+  // UNIFORM_CDF: low + (high - low) Phi(s)
+  const double w = h.prior_scale - h.prior_loc;
+  dxds = w * 0.3989422804014326779 * exp(-0.5 * s * s);
+  return h.prior_loc + w * 0.5 * erfc(-s * 0.7071067811865475244);
+}
+
+template <typename T>
+__device__ __forceinline__ double linked_scale(const sgmcmc_layout& L, const sgmcmc_segment* sp, double& dxds) {
+  dxds = 0.0;
+  if (sp->scale_link <= 0) return sp->prior_scale;
+  const sgmcmc_segment& h = L.segs[sp->scale_link - 1];
+  return hyper_value(h, (double)*(const T*)h.theta, dxds);
+}
+
+// the scale a segment's prior is evaluated with right now: its own constant, or the hyper segment's value
+__device__ __forceinline__ double current_scale(const sgmcmc_layout& L, const sgmcmc_segment& s) {
+  if (s.scale_link <= 0) return s.prior_scale;
+  double dxds;
+  return L.dtype == SGMCMC_F32 ? linked_scale<float>(L, &s, dxds) : linked_scale<double>(L, &s, dxds);
+}
+
+// d/dtheta[-log p(theta)/N] added to g, and (optionally) the un-normalised log-density into lp and
+// d/dscale[log p(theta)] into dls (hierarchical scales)
 template <typename T>
 struct PriorCoef {
   int kind;
+  bool linked;
   double loc, scale, df;
-  T locT, c_normal, c_laplace, c_t_num, c_t_den;
-  __device__ __forceinline__ void init(const sgmcmc_segment* sp, double num_data) {
+  T locT, c_normal, c_laplace, c_t_num, c_t_den, c_gn, inv_scaleT, beta_m1;
+  __device__ __forceinline__ void init(const sgmcmc_layout& L, const sgmcmc_segment* sp, double num_data) {
     kind = sp->prior_kind;
-    loc = sp->prior_loc; scale = sp->prior_scale;
+    loc = sp->prior_loc;
+    double dxds;
+    linked = sp->scale_link > 0;
+    scale = linked_scale<T>(L, sp, dxds);
     df = kind == SGMCMC_PRIOR_CAUCHY ? 1.0 : sp->prior_df;
     locT = (T)loc;
     c_normal = (T)(1.0 / (scale * scale * num_data));
     c_laplace = (T)(1.0 / (scale * num_data));
     c_t_num = (T)((df + 1.0) / num_data);
     c_t_den = (T)(df * scale * scale);
+    c_gn = (T)(df / (scale * num_data));   // GENNORM: df holds beta
+    c_hyper = 1.0 / num_data;
+    inv_scaleT = (T)(1.0 / scale);
+    beta_m1 = (T)(df - 1.0);
   }
-  __device__ __forceinline__ T apply(T g, T th, bool calc_logp, double& lp) const {
+  // FULL = false (the fused dense step kernel): only the four constant-scale families of BASELINE's configs;
+  // the host keeps models with other priors off that path (FusedDenseLeapfrog.supported)
+  template <bool FULL = true>
+  __device__ __forceinline__ T apply(T g, T th, bool calc_logp, double& lp, double& dls) const {
     if (kind == SGMCMC_PRIOR_NONE) return g;
+    if (FULL && kind >= SGMCMC_PRIOR_GAMMA_SOFTPLUS) {
+      // hyper-priors: th is the raw parameter s; everything in double (one element per tensor)
+      const double s = (double)th, sig = 1.0 / (1.0 + exp(-s)), x = s > 30.0 ? s : log1p(exp(s));
+      double dlp = 0.0, l = 0.0;                      // d log p / ds ; log p (normalised)
+      if (kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) {      // loc = concentration, scale = rate
+        dlp = ((loc - 1.0) / x - scale) * sig;
+        l = loc * log(scale) - lgamma(loc) + (loc - 1.0) * log(x) - scale * x;
+      } else if (kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) {   // loc = multiplier, scale = gamma
+        const double z = x * loc / scale;
+        dlp = -2.0 * z / (1.0 + z * z) * (loc / scale) * sig;
+        l = log(2.0 / (3.14159265358979323846 * scale)) - log1p(z * z);
+      } else {                                        // UNIFORM_CDF: constant density
+        l = -log(scale - loc);
+      }
+      if (calc_logp) lp += l;
+      return (T)((double)g - dlp * c_hyper);
+    }
     const T d = th - locT;
     if (kind == SGMCMC_PRIOR_NORMAL) {
       g = fma_t<T>(d, c_normal, g);
     } else if (kind == SGMCMC_PRIOR_LAPLACE) {
       const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
       g = fma_t<T>(sgn, c_laplace, g);
+    } else if (FULL && kind == SGMCMC_PRIOR_GENNORM) {
+      const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
+      const T z = (d < T(0) ? -d : d) * inv_scaleT;
+      g = fma_t<T>(sgn * (T)pow((double)z, (double)beta_m1), c_gn, g);
     } else {  // Student-t (df) and Cauchy (= Student-t with df = 1, set by PriorCoef::init)
       g = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g);
     }
-    if (calc_logp) {
-      const double z = ((double)th - loc) / scale;
-      if (kind == SGMCMC_PRIOR_NORMAL) lp += -0.5 * z * z;
-      else if (kind == SGMCMC_PRIOR_LAPLACE) lp += -fabs(z);
-      else lp += -0.5 * (df + 1.0) * log1p(z * z / df);
+    if (calc_logp || (FULL && linked)) {
+      const double dd = (double)th - loc, z = dd / scale;
+      if (kind == SGMCMC_PRIOR_NORMAL) { lp += -0.5 * z * z; dls += (z * z - 1.0) / scale; }
+      else if (kind == SGMCMC_PRIOR_LAPLACE) { lp += -fabs(z); dls += (fabs(z) - 1.0) / scale; }
+      else if (FULL && kind == SGMCMC_PRIOR_GENNORM) lp += -pow(fabs(z), df);
+      else { lp += -0.5 * (df + 1.0) * log1p(z * z / df); dls += ((df + 1.0) * z * z / (df + z * z) - 1.0) / scale; }
     }
     return g;
   }
+  double c_hyper;  // 1/N for the hyper-prior kinds
 };
 
 // fixed-order sum of the slices' partial gradients for the 4 elements at packed offset q
@@ -350,6 +430,12 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
   const double M = sp->M;
+  if (!PARTS && sp->g == nullptr) {
+    // raise_on_no_grad=False: a tensor without gradient is left untouched -- parameter, momentum,
+    // square_avg and its running scalars (the reference's `continue`, sgld.py:96-100)
+    if (threadIdx.x < SGMCMC_NSUMS) L.partials[chunk * SGMCMC_PSTRIDE + threadIdx.x] = 0.0;
+    return;
+  }
 
   Coef<T, KIND> C;
   C.grad_lr = (KIND == SGMCMC_SGLD) ? (T)(-A.bhn * M) : (T)(-.5 * A.grad_v * A.bhn * M);
@@ -380,7 +466,8 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
   const float* __restrict__ pp = PARTS ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
   PriorCoef<T> PC;
-  if (PARTS) PC.init(sp, G.num_data);
+  if (PARTS) PC.init(L, sp, G.num_data);
+  double dls_unused = 0.0;
 
   double acc[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
   double lp = 0.0;
@@ -407,7 +494,7 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       Item<T> mn, tn, vn;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
-        if (PARTS) g[it].x[l] = PC.apply(g[it].x[l], th[it].x[l], calc_logp, lp);
+        if (PARTS) g[it].x[l] = PC.template apply<false>(g[it].x[l], th[it].x[l], calc_logp, lp, dls_unused);
         if (C.do_clamp) g[it].x[l] = clamp_grad<T>(g[it].x[l], C.clampv);
         update_elem<T, KIND>(C, (T)z[l], g[it].x[l], m[it].x[l], th[it].x[l], v[it].x[l], mn.x[l],
                              tn.x[l], vn.x[l], acc);
@@ -440,7 +527,7 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
         if (l < n) {
-          if (PARTS) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, lp);
+          if (PARTS) g.x[l] = PC.template apply<false>(g.x[l], th.x[l], calc_logp, lp, dls_unused);
           if (C.do_clamp) g.x[l] = clamp_grad<T>(g.x[l], C.clampv);
           update_elem<T, KIND>(C, (T)z[l], g.x[l], m.x[l], th.x[l], v.x[l], mn.x[l], tn.x[l],
                                vn.x[l], acc);
@@ -541,6 +628,7 @@ __device__ __forceinline__ double segment_bookkeeping(const sgmcmc_layout& L, co
                                                       int seg, const sgmcmc_segment& s,
                                                       const double (&S)[SGMCMC_NSUMS]) {
   sgmcmc_seg_state* st = &L.state[seg];
+  if (s.g == nullptr) return st->delta_energy + st->point_energy;  // skipped tensor: state untouched
 #pragma unroll
   for (int k = 0; k < SGMCMC_NSUMS; ++k) st->sums[k] = S[k];
   const double d = (double)s.numel, M = s.M;
@@ -625,7 +713,7 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
       const double e = segment_bookkeeping(L, A, seg, s, S6);
       double lp = 0.0;
       if (with_lp)
-        L.state[seg].aux = lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s);
+        L.state[seg].aux = lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s, current_scale(L, s));
       if (seg - A.seg_begin < kSmallSegs) { seg_e[seg - A.seg_begin] = e; seg_lp[seg - A.seg_begin] = lp; }
     }
   }
@@ -708,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void restore_kernel(sgmcmc_layout L, int 
     const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
     if (n <= 0) break;
     store_guarded<T>(thp + j, load_guarded<T>(pth + j, n), n);  // verlet_sgld.py:64
-    store_guarded<T>(gp + j, load_guarded<T>(pg + j, n), n);    // :65
+    if (sp->g) store_guarded<T>(gp + j, load_guarded<T>(pg + j, n), n);    // :65
     if (restore_m) store_guarded<T>(mp + j, load_guarded<T>(pm + j, n), n);  // :66-69
   }
 }
@@ -722,7 +810,8 @@ __global__ __launch_bounds__(kThreads) void dot_kernel(sgmcmc_layout L, int whic
   const T* __restrict__ src = which == 2 ? (const T*)sp->g + cx.seg_off
                                          : (const T*)(which == 1 ? L.m : L.v) + cx.arena_off;
   double acc[1] = {0.0};
-  for (int it = 0; it < items_of(L); ++it) {
+  const bool absent = which == 2 && sp->g == nullptr;   // no gradient: contributes nothing
+  for (int it = 0; it < items_of(L) && !absent; ++it) {
     const int j = (it * kThreads + threadIdx.x) * 4;
     const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
     if (n <= 0) break;
@@ -757,14 +846,16 @@ __global__ __launch_bounds__(kThreads) void finalize_dot_kernel(sgmcmc_layout L,
 // d/dtheta of -log p(theta)/N and (optionally) log p(theta), element-wise families with scalar
 // loc/scale/df (SURVEY.md Appendix A "Priors").  The gradient is applied in the working precision
 // with one rounding for the factor and one fma into g; log p is evaluated and accumulated in fp64.
-__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s) {
-  // per-element normalising constant of the density
-  if (s.prior_kind == SGMCMC_PRIOR_NORMAL) return -log(s.prior_scale) - 0.9189385332046727418;
-  if (s.prior_kind == SGMCMC_PRIOR_LAPLACE) return -log(2.0 * s.prior_scale);
+__device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s, double scale) {
+  // per-element normalising constant of the density; the hyper-prior kinds
+  // accumulate their full log-density element by element and need none
+  if (s.prior_kind == SGMCMC_PRIOR_NORMAL) return -log(scale) - 0.9189385332046727418;
+  if (s.prior_kind == SGMCMC_PRIOR_LAPLACE) return -log(2.0 * scale);
   if (s.prior_kind == SGMCMC_PRIOR_STUDENT_T)
-    return -log(s.prior_scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
+    return -log(scale) - 0.5 * log(s.prior_df) - 0.5723649429247000870 -
            lgamma(0.5 * s.prior_df) + lgamma(0.5 * (s.prior_df + 1.0));
-  if (s.prior_kind == SGMCMC_PRIOR_CAUCHY) return -log(s.prior_scale) - 1.1447298858494001741;  // -ln(pi sigma)
+  if (s.prior_kind == SGMCMC_PRIOR_CAUCHY) return -log(scale) - 1.1447298858494001741;  // -ln(pi sigma)
+  if (s.prior_kind == SGMCMC_PRIOR_GENNORM) return -log(2.0 * scale) - lgamma(1.0 / s.prior_df) + log(s.prior_df);
   return 0.0;
 }
 
@@ -775,13 +866,14 @@ __device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_da
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
   const bool parts = G.gpart != nullptr;
-  double acc[1] = {0.0};
-  if (sp->prior_kind != SGMCMC_PRIOR_NONE || parts) {
+  const bool linked = sp->scale_link > 0;
+  double acc[2] = {0.0, 0.0};   // log-density partial; d/dscale of it (hierarchical scales)
+  if ((sp->prior_kind != SGMCMC_PRIOR_NONE || parts) && sp->g != nullptr) {
     T* __restrict__ gp = (T*)sp->g + cx.seg_off;
     const T* __restrict__ thp = (const T*)sp->theta + cx.seg_off;
     const float* __restrict__ pp = parts ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
     PriorCoef<T> PC;
-    PC.init(sp, num_data);
+    PC.init(L, sp, num_data);
     for (int it = 0; it < items_of(L); ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
       const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
@@ -790,12 +882,33 @@ __device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_da
       const Item<T> th = load_guarded<T>(thp + j, n);
 #pragma unroll
       for (int l = 0; l < 4; ++l)
-        if (l < n) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, acc[0]);
+        if (l < n) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, acc[0], acc[1]);
       store_guarded<T>(gp + j, g, n);
     }
   }
-  if (calc_logp) block_reduce_store<1>(acc, L.partials + chunk * SGMCMC_PSTRIDE + 6);
+  if (calc_logp || linked) block_reduce_store<2>(acc, L.partials + chunk * SGMCMC_PSTRIDE + 6);
   if (parts) publish_batch_stats(L, G);
+}
+
+// Hierarchical scales: the hyper segment h (one element, raw parameter s) of every linked weight segment w gets
+//   g_h += -(1/N) * (sum_j d/dscale log p(theta_wj)) * dx/ds        (the chain rule through x = value(s))
+// from the per-chunk partials the prior kernel left in partials[.][7].  One workgroup; thread t owns the
+// linked segments t, t + 256, ... and sums their chunks in chunk order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void hyper_link_kernel(sgmcmc_layout L, double num_data) {
+  for (int w = threadIdx.x; w < L.n_seg; w += kThreads) {
+    const sgmcmc_segment s = L.segs[w];
+    if (s.scale_link <= 0) continue;
+    const sgmcmc_segment h = L.segs[s.scale_link - 1];
+    if (h.g == nullptr) continue;
+    double D = 0.0;
+    const int64_t n = seg_chunks(L, s);
+    for (int64_t c = 0; c < n; ++c) D += L.partials[(s.first_chunk + c) * SGMCMC_PSTRIDE + 7];
+    double dxds;
+    hyper_value(h, (double)*(const T*)h.theta, dxds);
+    T* gh = (T*)h.g;
+    *gh = (T)((double)*gh - D * dxds / num_data);
+  }
 }
 
 template <typename T>
@@ -816,7 +929,7 @@ __global__ __launch_bounds__(kThreads) void finalize_prior_kernel(sgmcmc_layout 
   double S[1];
   segment_reduce<1>(L.partials + 6, s.first_chunk, seg_chunks(L, s), SGMCMC_PSTRIDE, S);
   if (threadIdx.x != 0) return;
-  L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + (double)s.numel * prior_log_norm(s);
+  L.state[seg].aux = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[0] + (double)s.numel * prior_log_norm(s, current_scale(L, s));
 }
 
 __global__ void total_prior_kernel(sgmcmc_layout L) {
@@ -853,13 +966,13 @@ template <typename T, int KIND, bool VEC, int ITEMS>
 void launch_step_mode(const sgmcmc_layout& L, const sgmcmc_step_args& A, const sgmcmc_step_args* Ad,
                       const GradParts* G, hipStream_t s) {
   const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
-  if (G && Ad) hipLaunchKernelGGL((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
-  else if (G) hipLaunchKernelGGL((step_kernel_parts_val<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A, *G);
-  else if (Ad) hipLaunchKernelGGL((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
+  if (G && Ad) SGMCMC_LAUNCH((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
+  else if (G) SGMCMC_LAUNCH((step_kernel_parts_val<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A, *G);
+  else if (Ad) SGMCMC_LAUNCH((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
   else if (VEC && ITEMS == 4 &&
            (double)L.n_chunks * (double)L.chunk_elems * sizeof(T) * 7.0 > 224.0 * 1024 * 1024)
-    hipLaunchKernelGGL((step_kernel_stream<T, KIND>), grid, block, 0, s, L, A);
-  else hipLaunchKernelGGL((step_kernel<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A);
+    SGMCMC_LAUNCH((step_kernel_stream<T, KIND>), grid, block, 0, s, L, A);
+  else SGMCMC_LAUNCH((step_kernel<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A);
 }
 
 template <typename T, bool VEC, int ITEMS>
@@ -902,11 +1015,11 @@ void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sg
   const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)),
       block(small && A->seg_end - A->seg_begin > 4 ? 1024u : (unsigned)kThreads);
   if (Ad) {
-    if (small) hipLaunchKernelGGL(finalize_small_kernel_indirect, grid, block, 0, s, *L, Ad);
-    else hipLaunchKernelGGL(finalize_step_kernel_indirect, grid, block, 0, s, *L, Ad);
+    if (small) SGMCMC_LAUNCH(finalize_small_kernel_indirect, grid, block, 0, s, *L, Ad);
+    else SGMCMC_LAUNCH(finalize_step_kernel_indirect, grid, block, 0, s, *L, Ad);
   } else {
-    if (small) hipLaunchKernelGGL(finalize_small_kernel, grid, block, 0, s, *L, *A);
-    else hipLaunchKernelGGL(finalize_step_kernel, grid, block, 0, s, *L, *A);
+    if (small) SGMCMC_LAUNCH(finalize_small_kernel, grid, block, 0, s, *L, *A);
+    else SGMCMC_LAUNCH(finalize_step_kernel, grid, block, 0, s, *L, *A);
   }
 }
 
@@ -922,10 +1035,10 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
                       void* ev_start, void* ev_stop) {
   SGMCMC_FRESH_ERROR_STATE();
   hipStream_t s = (hipStream_t)stream;
-  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, s);
+  if (ev_start && ev_stop) { sgmcmc_timing::e0 = (hipEvent_t)ev_start; sgmcmc_timing::e1 = (hipEvent_t)ev_stop; }
   const int rc = launch_step(L, A, nullptr, nullptr, s);
+  sgmcmc_timing::e0 = sgmcmc_timing::e1 = nullptr;
   if (rc) return rc;
-  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, s);
   launch_finalize(L, A, nullptr, s);
   return (int)hipGetLastError();
 }
@@ -993,6 +1106,18 @@ int sgmcmc_event_create(void** ev) {
 
 int sgmcmc_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 
+int sgmcmc_time_next_launch(void* ev_start, void* ev_stop) {
+  if (!ev_start || !ev_stop) return (int)hipErrorInvalidValue;
+  sgmcmc_timing::e0 = (hipEvent_t)ev_start;
+  sgmcmc_timing::e1 = (hipEvent_t)ev_stop;
+  return 0;
+}
+
+int sgmcmc_event_record(void* ev, void* stream) {
+  SGMCMC_FRESH_ERROR_STATE();
+  return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+}
+
 int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
   SGMCMC_FRESH_ERROR_STATE();
   hipError_t err = hipEventSynchronize((hipEvent_t)ev_stop);
@@ -1007,9 +1132,9 @@ int sgmcmc_sample_momentum(const sgmcmc_layout* L, double std, double keep, uint
   hipStream_t s = (hipStream_t)stream_;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   if (L->dtype == SGMCMC_F32)
-    hipLaunchKernelGGL(sample_momentum_kernel<float>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
+    SGMCMC_LAUNCH(sample_momentum_kernel<float>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
   else
-    hipLaunchKernelGGL(sample_momentum_kernel<double>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
+    SGMCMC_LAUNCH(sample_momentum_kernel<double>, grid, block, 0, s, *L, std, keep, seed, stream, draw);
   return (int)hipGetLastError();
 }
 
@@ -1020,16 +1145,16 @@ int sgmcmc_restore(const sgmcmc_layout* L, int restore_momentum, uint32_t flags,
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   if (L->dtype == SGMCMC_F32)
-    hipLaunchKernelGGL(restore_kernel<float>, grid, block, 0, s, *L, restore_momentum);
+    SGMCMC_LAUNCH(restore_kernel<float>, grid, block, 0, s, *L, restore_momentum);
   else
-    hipLaunchKernelGGL(restore_kernel<double>, grid, block, 0, s, *L, restore_momentum);
+    SGMCMC_LAUNCH(restore_kernel<double>, grid, block, 0, s, *L, restore_momentum);
   return (int)hipGetLastError();
 }
 
 static int launch_dot(const sgmcmc_layout* L, int which, double clampv, hipStream_t s) {
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
-  if (L->dtype == SGMCMC_F32) hipLaunchKernelGGL(dot_kernel<float>, grid, block, 0, s, *L, which, clampv);
-  else hipLaunchKernelGGL(dot_kernel<double>, grid, block, 0, s, *L, which, clampv);
+  if (L->dtype == SGMCMC_F32) SGMCMC_LAUNCH(dot_kernel<float>, grid, block, 0, s, *L, which, clampv);
+  else SGMCMC_LAUNCH(dot_kernel<double>, grid, block, 0, s, *L, which, clampv);
   return (int)hipGetLastError();
 }
 
@@ -1042,9 +1167,9 @@ int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, doubl
   hipStream_t s = (hipStream_t)stream;
   int err = launch_dot(L, kind == SGMCMC_HMC ? 1 : 2, grad_clamp, s);
   if (err) return err;
-  hipLaunchKernelGGL(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L,
+  SGMCMC_LAUNCH(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L,
                      kind == SGMCMC_HMC ? 2 : 1, num_data, b2h2);
-  hipLaunchKernelGGL(total_energy_kernel, dim3(1), dim3(64), 0, s, *L);
+  SGMCMC_LAUNCH(total_energy_kernel, dim3(1), dim3(64), 0, s, *L);
   return (int)hipGetLastError();
 }
 
@@ -1055,25 +1180,28 @@ int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* 
   hipStream_t s = (hipStream_t)stream;
   int err = launch_dot(L, which, 0.0, s);
   if (err) return err;
-  hipLaunchKernelGGL(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L, 0, 0.0, 0.0);
+  SGMCMC_LAUNCH(finalize_dot_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L, 0, 0.0, 0.0);
   return (int)hipGetLastError();
 }
 
 int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob, uint32_t flags,
                       void* stream) {
   SGMCMC_FRESH_ERROR_STATE();
-  (void)flags;
   if (!L || L->n_chunks <= 0 || !(num_data > 0)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
   if (L->dtype == SGMCMC_F32)
-    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
+    SGMCMC_LAUNCH(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
   else
-    hipLaunchKernelGGL(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
+    SGMCMC_LAUNCH(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
+  if (flags & SGMCMC_PRIOR_HAS_LINKS) {
+    if (L->dtype == SGMCMC_F32) SGMCMC_LAUNCH(hyper_link_kernel<float>, dim3(1), block, 0, s, *L, num_data);
+    else SGMCMC_LAUNCH(hyper_link_kernel<double>, dim3(1), block, 0, s, *L, num_data);
+  }
   if (calc_log_prob) {
-    hipLaunchKernelGGL(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
-    hipLaunchKernelGGL(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
+    SGMCMC_LAUNCH(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
+    SGMCMC_LAUNCH(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
   }
   return (int)hipGetLastError();
 }
@@ -1090,13 +1218,13 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch, num_data};
   if (A_dev)
-    hipLaunchKernelGGL(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
+    SGMCMC_LAUNCH(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
   else {
     const int calc = (int)((flags & SGMCMC_CALC_METRICS) != 0);
-    hipLaunchKernelGGL(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc, G);
+    SGMCMC_LAUNCH(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc, G);
     if (calc) {  // no sampler launch follows to finish the log-prior: do it here
-      hipLaunchKernelGGL(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
-      hipLaunchKernelGGL(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
+      SGMCMC_LAUNCH(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
+      SGMCMC_LAUNCH(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
     }
   }
   return (int)hipGetLastError();
@@ -1106,7 +1234,7 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
                          uint64_t draw, uint32_t purpose, void* stream_) {
   SGMCMC_FRESH_ERROR_STATE();
   if (!out || n <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(debug_normals_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, out,
+  SGMCMC_LAUNCH(debug_normals_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream_, out,
                      start, n, seed, stream, draw, purpose);
   return (int)hipGetLastError();
 }

@@ -71,6 +71,8 @@ class FusedDenseLeapfrog(_ReportSlots):
             return False
         if eng.dtype != torch.float32 or len(optimizer.param_groups) != 1:
             return False
+        if eng.prior_links or eng.prior_max_kind > _hip.PRIOR_CAUCHY:
+            return False       # the step kernel's in-flight prior covers the constant-scale families only
         want = [t for l in lin for t in (l.weight_prior.p, l.bias_prior.p)]
         if len(want) != len(eng.params) or any(a is not b for a, b in zip(want, eng.params)):
             return False

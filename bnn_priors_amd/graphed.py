@@ -26,6 +26,7 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
+from . import conv as _conv
 from . import pool as _pool
 
 from . import _hip
@@ -104,9 +105,12 @@ class GraphedLeapfrog(_ReportSlots):
 
     def _body(self, capturing, metrics):
         self.opt.zero_grad()
-        f = self.pot._logits(self.x)
-        loss = _pool.cross_entropy(f, self.y)
-        loss.backward()
+        with _conv.deferring():
+            f = self.pot._logits(self.x)
+            loss = _pool.cross_entropy(f, self.y)
+            loss.backward()
+        with torch.no_grad():
+            self.opt._prepare_hyper_grads()
         self.eng.refresh(self.opt._preconditioners(), defer_upload=capturing)
         self.eng.prior_grad(self.pot.N, metrics)
         self.eng.step_indirect(self._A_host, self.args_dev.data_ptr())
@@ -259,9 +263,11 @@ class GraphedAccumulate:
         params = self.eng.params
         for p in params:
             p.grad = None
-        this = _pool.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
-        this.backward()
-        torch._foreach_add_(self.grads, [p.grad for p in params])
+        with _conv.deferring():
+            this = _pool.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
+            this.backward()
+        got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none
+        torch._foreach_add_([a for a, _ in got], [g for _, g in got])
         self.loss += this.detach().double()
 
     def _body(self):

@@ -254,7 +254,10 @@ class SGLDRunner:
             return None
         if self._graphed is None:
             pot = self._potential()
-            if not pot.fast or pot.leftover or len(self.optimizer.param_groups) != 1:
+            # the graphed metric rows read the transition's energy total from scalars[3], which only the
+            # single-workgroup ("small") finalize writes: arenas beyond 4096 chunks keep the eager path
+            if (not pot.fast or pot.leftover or len(self.optimizer.param_groups) != 1
+                    or not self.optimizer.engine.small_finalize):
                 self._graphed = False
                 return None
             from .graphed import GraphedLeapfrog
@@ -312,7 +315,8 @@ class SGLDRunner:
                 r, state = row.get()
                 if r["nonfinite"]:
                     eng.scalars[1].zero_()
-                    raise ValueError("Potential is NaN")
+                    raise ValueError("Gradient is not finite" if self.optimizer.raise_on_nan
+                                     else "Potential is NaN")
                 r["potential"] = r["loss"] - r["log_prior"] / self.eff_num_data
                 eng._state_host = state          # what store_metrics reads the per-tensor values from
                 try:
@@ -341,6 +345,8 @@ class SGLDRunner:
                     store_metrics = (i == 0 or step % self.metrics_skip == 0)
                     initial_step = (step == 0 or (i == 0 and self._is_sampling_epoch(epoch - 1)))
                     self.step(step, x, y, store_metrics=store_metrics, initial_step=initial_step)
+                # rows still in flight were produced with the CURRENT preconditioners: log them first
+                self._drain_rows()
                 if self.precond_update is not None and epoch % self.precond_update == 0:
                     self.optimizer.update_preconditioner()
                 self._check_finite()
@@ -380,9 +386,14 @@ class SGLDRunner:
         return res
 
     def _check_finite(self):
+        """The reference tests ``isnan(potential)`` after every gradient (inference.py:221) and, for HMC
+        (``raise_on_nan=True``, mcmc/hmc.py:25-27), every gradient tensor inside ``step`` (sgld.py:101-104).
+        Both are one device-side flag here (the sum of squared gradients of some tensor was not finite),
+        tested whenever metrics are stored and at every epoch end: the same ``ValueError``, at most
+        ``metrics_skip`` steps later and without a host synchronisation per step."""
         self._drain_rows()
         if self.optimizer.engine.nonfinite_seen():
-            raise ValueError("Potential is NaN")
+            raise ValueError("Gradient is not finite" if self.optimizer.raise_on_nan else "Potential is NaN")
 
     def _potential(self):
         try:
@@ -541,5 +552,6 @@ class HMCRunner(VerletSGLDRunner):
         assert self.momentum == 1.0, "HMC only works with momentum=1."
         assert self.descent_epochs == 0, "HMC not implemented for descent epochs with temp=0."
         kw = self._sampler_kwargs()
-        return mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
-                        raise_on_nan=False, **kw)
+        opt = mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data, **kw)
+        opt.defer_nan_check = True      # raise_on_nan stays True (hmc.py:25-27); tested by _check_finite
+        return opt

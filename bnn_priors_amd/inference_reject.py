@@ -172,8 +172,12 @@ class HMCRunnerReject(VerletSGLDRunnerReject):
         assert self.temperature == 1.0, "HMC only implemented for temperature=1."
         assert self.momentum == 1.0, "HMC only works with momentum=1."
         assert self.descent_epochs == 0, "HMC not implemented for descent epochs with temp=0."
-        return mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
-                        raise_on_nan=False, **self._sampler_kwargs())
+        opt = mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
+                       **self._sampler_kwargs())
+        # raise_on_nan keeps the reference's default (True, mcmc/hmc.py:25-27); inside a runner the test is the
+        # device-side flag read at metric steps and epoch ends (SGLDRunner._check_finite), not a sync per step
+        opt.defer_nan_check = True
+        return opt
 
 
 class SGLDRunnerReject(VerletSGLDRunnerReject):

@@ -234,15 +234,25 @@ class Engine:
         ev = getattr(self, "_upload_event", None)
         return ev is not None and not ev.query()
 
-    def set_priors(self, specs):
-        "specs[i] = None or (kind, loc, scale, df): enable the in-kernel prior gradient"
+    def set_priors(self, specs, links=None):
+        """specs[i] = None or (kind, loc, scale, shape-parameter): enable the in-kernel prior gradient;
+        links[i] = index of the hyper segment whose VALUE is segment i's scale (hierarchical priors), or None"""
+        self.prior_links = False
         for i, sp in enumerate(specs):
             row = self.seg_host[i]
+            row["scale_link"] = 0
             if sp is None:
                 row["prior_kind"] = _hip.PRIOR_NONE
             else:
                 row["prior_kind"], row["prior_loc"], row["prior_scale"], row["prior_df"] = sp
+                if links is not None and links[i] is not None:
+                    row["scale_link"] = links[i] + 1
+                    self.prior_links = True
+        self.prior_max_kind = max([0] + [int(sp[0]) for sp in specs if sp is not None])
         self._seg_dirty = True
+
+    prior_links = False      # some segment takes its scale from a hyper segment
+    prior_max_kind = 0
 
     # ------------------------------------------------------------------ deferred finalize
     # The fused dense step leaves a transition's per-segment bookkeeping pending (it is not an
@@ -365,7 +375,8 @@ class Engine:
     def prior_grad(self, num_data, calc_log_prob):
         self.flush()
         _hip.check(self.lib.sgmcmc_prior_grad(ctypes.byref(self.layout), float(num_data),
-                                              int(bool(calc_log_prob)), 0, self.stream()),
+                                              int(bool(calc_log_prob)),
+                                              _hip.PRIOR_HAS_LINKS if self.prior_links else 0, self.stream()),
                    "sgmcmc_prior_grad")
         if calc_log_prob:
             self._touch()

@@ -86,8 +86,12 @@ class SGLD(torch.optim.Optimizer):
                     view.copy_(t)
                     dict.__setitem__(st, key, view)
 
+    # set by the runners: the non-finite flag stays on the device and is tested at metric steps / epoch
+    # ends (inference.SGLDRunner._check_finite) instead of with one host sync after every launch
+    defer_nan_check = False
+
     def _check_nan(self):
-        if self.raise_on_nan and self._engine.nonfinite_seen():
+        if self.raise_on_nan and not self.defer_nan_check and self._engine.nonfinite_seen():
             raise ValueError("Gradient is not finite")
 
     def _launch(self, kind, flags, group_scalars, needs_momentum=True):
@@ -97,13 +101,8 @@ class SGLD(torch.optim.Optimizer):
         if needs_momentum and not eng.momentum_ready:
             raise RuntimeError("No 'momentum_buffer' stored in state. "
                                "Perhaps you forgot to call `sample_momentum`?")
-        if any(p.grad is None for p in eng.params):
-            # raise_on_no_grad=False: the reference skips such tensors (sgld.py:96-100);
-            # the fused sweep cannot, so give them a zero gradient for this launch
-            for p in eng.params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            eng.refresh(self._preconditioners())
+        # raise_on_no_grad=False: tensors whose grad is None carry a null gradient pointer in the segment
+        # table and the kernels leave them untouched, as the reference's `continue` does (sgld.py:96-100)
         self._adopt_foreign_momentum()
         draw = eng.next_draw()
         for gi, group in enumerate(self.param_groups):
@@ -111,31 +110,130 @@ class SGLD(torch.optim.Optimizer):
             eng.step(gi, kind, flags, draw, grad_clamp=self.grad_clamp, **sc)
         self._check_nan()
 
+    # ------------------------------------------------------------------ checkpointing
+    # (The reference never checkpoints its optimizer; torch's own state_dict / load_state_dict would lose
+    #  what lives on the device: the per-tensor running scalars, and the arena-backed SegState wrappers.)
+    _TENSOR_KEYS = ("momentum_buffer", "square_avg", "prev_parameter", "prev_grad", "prev_momentum_buffer")
+
+    def state_dict(self):
+        """``torch.optim.Optimizer.state_dict`` plus the device-resident per-tensor scalars
+        (``delta_energy``, ``prev_new_momentum_delta``, ``est_temperature``, ``est_config_temp``) as plain
+        floats in each tensor's state, and the engine's Philox position under ``"sgmcmc_engine"``."""
+        eng = self._engine
+        eng.flush()
+        lazy = {}
+        for i, p in enumerate(eng.params):
+            st = self.state[p]
+            extra = {k: st[k] for k in SegState._LAZY if k in st}
+            if extra:
+                lazy[i] = extra
+        for i, extra in lazy.items():               # materialise, snapshot, remove again
+            for k, v in extra.items():
+                dict.__setitem__(self.state[eng.params[i]], k, v)
+        try:
+            sd = super().state_dict()
+            sd["state"] = {k: {kk: (vv.clone() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()}
+                           for k, v in sd["state"].items()}
+        finally:
+            for i, extra in lazy.items():
+                for k in extra:
+                    dict.pop(self.state[eng.params[i]], k, None)
+        sd["sgmcmc_engine"] = dict(seed=eng.seed, chain_id=eng.chain_id, draw=eng.draw,
+                                   momentum_ready=eng.momentum_ready, energy_ready=eng.energy_ready,
+                                   metrics_ready=eng.metrics_ready)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Restores a ``state_dict()``: tensors are copied INTO the arenas (the views stay the state's
+        tensors), the running scalars go back to the device array, the Philox counter continues."""
+        import numpy as np
+        state_dict = dict(state_dict)
+        meta = state_dict.pop("sgmcmc_engine", None)
+        super().load_state_dict(state_dict)
+        eng = self._engine
+        eng.flush()
+        host = eng.state_dev.cpu().numpy().reshape(eng.n_seg, -1).copy()
+        views = dict(momentum_buffer=eng.momentum_view, square_avg=eng.square_avg_view)
+        for i, p in enumerate(eng.params):
+            loaded = dict(self.state.get(p, {}))
+            st = self.state[p] = SegState(eng, i)
+            if any(k.startswith("prev_") for k in loaded):
+                eng.ensure_prev()
+            prev = dict(prev_parameter=lambda j: eng._view(eng.prev_theta, j),
+                        prev_grad=lambda j: eng._view(eng.prev_g, j),
+                        prev_momentum_buffer=lambda j: eng._view(eng.prev_m, j))
+            for k, v in loaded.items():
+                if k in self._TENSOR_KEYS:
+                    view = (views.get(k) or prev[k])(i)
+                    view.copy_(v)
+                    dict.__setitem__(st, k, view)
+                elif k in SegState._LAZY:
+                    host[i, _hip.SEG_STATE_FIELDS.index(SegState._LAZY[k][0])] = float(v)
+                else:
+                    st[k] = v
+            st.setdefault('square_avg', eng.square_avg_view(i))
+        eng.state_dev.copy_(torch.from_numpy(np.ascontiguousarray(host).reshape(-1)))
+        eng._touch()
+        eng._precond_dirty = eng._seg_dirty = True
+        any_loaded = [dict.__contains__(self.state[p], "momentum_buffer") for p in eng.params]
+        eng.momentum_ready = all(any_loaded) and bool(any_loaded)
+        if meta is not None:
+            eng.seed, eng.chain_id, eng.draw = int(meta["seed"]), int(meta["chain_id"]), int(meta["draw"])
+            eng.energy_ready, eng.metrics_ready = bool(meta["energy_ready"]), bool(meta["metrics_ready"])
+            eng.momentum_ready = eng.momentum_ready and bool(meta["momentum_ready"])
+
     # ------------------------------------------------------------------ fused priors
     def fuse_priors(self, model):
         """Let the engine differentiate the element-wise priors of ``model`` in one kernel
         (``add_prior_gradient``) instead of autograd.  Returns the Prior modules that can NOT be
         fused (tensor-valued or learnable loc/scale, other families): their ``log_prob`` must stay
-        in the autograd potential.  Parameters without a prior (e.g. BatchNorm) get none."""
+        in the autograd potential.  Parameters without a prior (e.g. BatchNorm) get none.
+        Hierarchical priors (``prior/hierarchical.py``): the weight tensor's row is linked to the
+        segment of its one-element scale hyper-parameter; that parameter only ever receives a gradient
+        from the priors, so ``add_prior_gradient`` gives it a zeroed ``.grad`` to accumulate into."""
         from ..prior import named_priors
+        eng = self._engine
         by_param = {id(pr.p): pr for _, pr in named_priors(model)}
-        specs, leftover = [], []
-        for p in self._engine.params:
-            pr = by_param.pop(id(p), None)
-            sp = pr.fused_spec() if pr is not None else None
-            if pr is not None and sp is None:
-                leftover.append(pr)
-            specs.append(sp)
+        priors = [by_param.pop(id(p), None) for p in eng.params]
+        specs = [pr.fused_spec() if pr is not None else None for pr in priors]
+        links = [None] * len(specs)
+        claimed = {}
+        for i, pr in enumerate(priors):
+            hyper = pr.scale_link() if (pr is not None and specs[i] is not None) else None
+            if hyper is None:
+                continue
+            h = eng.index.get(id(hyper.p))
+            # the hyper segment must be this optimizer's, fused itself, and feed exactly one tensor
+            if h is None or specs[h] is None or h in claimed:
+                specs[i] = None
+                continue
+            links[i] = claimed[h] = h
+        leftover = [pr for pr, sp in zip(priors, specs) if pr is not None and sp is None]
         leftover.extend(by_param.values())   # priors whose .p this optimizer does not own
-        self._engine.set_priors(specs)
+        eng.set_priors(specs, links)
+        self._hyper_params = [eng.params[h] for h in sorted(claimed)]
+        self._hyper_grads = [torch.zeros_like(p) for p in self._hyper_params]
         self._fused_any = any(sp is not None for sp in specs)
         return leftover
+
+    def _prepare_hyper_grads(self):
+        "scale hyper-parameters take no likelihood gradient: a persistent zeroed buffer stands in for None"
+        hyper = getattr(self, "_hyper_params", None)
+        if not hyper:
+            return
+        fresh = [g for p, g in zip(hyper, self._hyper_grads) if p.grad is None]
+        if fresh:
+            torch._foreach_zero_(fresh)
+        for p, g in zip(hyper, self._hyper_grads):
+            if p.grad is None:
+                p.grad = g
 
     @torch.no_grad()
     def add_prior_gradient(self, calc_log_prior=False):
         """p.grad += d/dtheta[-log p(theta)/N] for every fused prior (one launch); with
         ``calc_log_prior`` the summed log-density is left on the device (``fused_log_prior()``)."""
         eng = self._engine
+        self._prepare_hyper_grads()
         eng.refresh(self._preconditioners(), raise_on_no_grad=True)
         nd = self.param_groups[0]['num_data']
         assert all(g['num_data'] == nd for g in self.param_groups), "unclear which `num_data` to use"

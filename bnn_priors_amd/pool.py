@@ -22,6 +22,8 @@ def supported(x, bias):
 class _BiasReluPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias):
+        if bias is not None:
+            _conv._note_use(bias)
         x = x.contiguous()
         n, c, h, w = x.shape
         y = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
@@ -54,7 +56,7 @@ class _BiasReluPool(torch.autograd.Function):
             _hip.check(err, "sgmcmc_bias_relu_pool_bwd")
         if not want_b:
             return dx, None
-        if _conv.DEFER_REDUCE and bias.is_leaf and bias.grad is None:
+        if _conv._may_defer(bias):
             # summed with the convolutions' weight-gradient slabs at the end of the backward pass
             torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
             _conv._pending.append((part, db, part.shape[0]))
@@ -100,6 +102,7 @@ def _reduce_rows(slabs, out, defer):
 class _PoolLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, weight, bias):
+        _conv._note_use(*((weight,) if bias is None else (weight, bias)))
         h, weight = h.contiguous(), weight.contiguous()
         n, c, plane, k = h.shape[0], h.shape[1], h.shape[2] * h.shape[3], weight.shape[0]
         pooled = torch.empty((n, c), dtype=torch.float32, device=h.device)
@@ -131,9 +134,9 @@ class _PoolLinear(torch.autograd.Function):
             _hip.check(err, "sgmcmc_pool_linear_bwd")
         dw = db = None
         if want_w:
-            dw = _reduce_rows(sw, torch.empty_like(weight), _conv.DEFER_REDUCE and weight.is_leaf and weight.grad is None)
+            dw = _reduce_rows(sw, torch.empty_like(weight), _conv._may_defer(weight))
         if want_b:
-            db = _reduce_rows(sb, torch.empty_like(bias), _conv.DEFER_REDUCE and bias.is_leaf and bias.grad is None)
+            db = _reduce_rows(sb, torch.empty_like(bias), _conv._may_defer(bias))
         return dh, dw, db
 
 

@@ -18,6 +18,7 @@ Nothing here synchronises with the host; callers ``.item()`` what they log.
 import torch
 import torch.nn.functional as F
 
+from . import conv as _conv
 from . import pool as _pool
 
 from .models.base import ClassificationModel
@@ -54,10 +55,11 @@ class Potential:
             loss, log_prior, potential, accs, _ = self.model.split_potential_and_acc(x, y, self.N)
             potential.backward()
             return loss, log_prior, potential, accs.mean()
-        f = self._logits(x)
-        loss = _pool.cross_entropy(f, y)
-        extra = self._leftover_log_prior()
-        (loss if extra is None else loss - extra / self.N).backward()
+        with _conv.deferring():      # this pass's convolution weight-gradient slabs: one reduction at its end
+            f = self._logits(x)
+            loss = _pool.cross_entropy(f, y)
+            extra = self._leftover_log_prior()
+            (loss if extra is None else loss - extra / self.N).backward()
         self.opt.add_prior_gradient(calc_log_prior=want_metrics)
         if not want_metrics:
             return loss.detach(), None, None, None
@@ -102,6 +104,7 @@ class Potential:
             if acc is not None:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:
+                # (gradients accumulate into existing .grad tensors here, so nothing is deferred)
                 this = _pool.cross_entropy(self._logits(x), y, reduction="sum") / self.N
                 this.backward()
                 loss = loss + this.detach().double()

@@ -71,20 +71,36 @@ class Prior(nn.Module):
     def forward(self):
         return self.p
 
+    _shape_arg = "df"      # name of the family's extra shape argument, if it has one
+
+    def scale_link(self):
+        "the Prior module that produces this prior's scale (hierarchical priors), or None"
+        sc = getattr(self, "scale", None)
+        return sc if isinstance(sc, Prior) else None
+
     def fused_spec(self):
-        """(kind, loc, scale, df) with python floats when the prior is an
-        element-wise family with scalar loc/scale buffers, else None."""
+        """(kind, loc, scale, shape-parameter) with python floats when the prior is an element-wise
+        family the HIP hook knows, with a plain-number loc and either a plain-number scale or a scale
+        produced by a one-element hyper-prior the hook also knows (then scale is NaN here and the
+        caller resolves ``scale_link()`` to a segment); else None."""
         if self.fused_kind is None:
             return None
         loc, scale = getattr(self, "loc", None), getattr(self, "scale", None)
-        if not (isinstance(loc, torch.Tensor) and isinstance(scale, torch.Tensor)):
+        if not isinstance(loc, torch.Tensor) or loc.numel() != 1 or isinstance(loc, nn.Parameter):
             return None
-        if loc.numel() != 1 or scale.numel() != 1 or isinstance(loc, nn.Parameter) \
-                or isinstance(scale, nn.Parameter):
+        link = self.scale_link()
+        if link is not None:
+            if link.p.numel() != 1 or link.fused_spec() is None or self.fused_kind not in (1, 2, 3):
+                return None
+            scale_value = float("nan")
+        else:
+            if not isinstance(scale, torch.Tensor) or scale.numel() != 1 or isinstance(scale, nn.Parameter):
+                return None
+            scale_value = float(scale)
+        extra = getattr(self, self._shape_arg, None)
+        if isinstance(extra, (Prior, nn.Parameter)) or (isinstance(extra, torch.Tensor) and extra.numel() != 1):
             return None
-        df = getattr(self, "df", None)
-        df = float(df) if df is not None else 0.0
-        return self.fused_kind, float(loc), float(scale), df
+        return self.fused_kind, float(loc), scale_value, (float(extra) if extra is not None else 0.0)
 
 
 def named_priors(module):

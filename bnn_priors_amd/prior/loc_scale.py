@@ -1,18 +1,19 @@
 """Element-wise location/scale priors used by the BASELINE configs.
 
 Reference: ``bnn_priors/prior/loc_scale.py:21-103`` (Normal :34, Laplace :66,
-Cauchy :70, StudentT :74-77, Improper :93-96).  Closed forms of log p and its
+Cauchy :70, StudentT :74-77, GenNorm :80-83, Improper :93-96).  Closed forms of log p and its
 gradient, which the fused HIP prior hook implements, are in SURVEY.md
 Appendix A and checked in tests/test_priors.py.
 """
 import torch.distributions as td
 
 from .base import Prior
+from .distributions import GeneralizedNormal
 
-__all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "Improper", "get_prior",
-           "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T", "FUSED_CAUCHY")
+__all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "GenNorm", "Improper", "get_prior",
+           "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T", "FUSED_CAUCHY", "FUSED_GENNORM")
 
-FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T, FUSED_CAUCHY = 0, 1, 2, 3, 4
+FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T, FUSED_CAUCHY, FUSED_GENNORM = 0, 1, 2, 3, 4, 5
 
 
 class LocScale(Prior):
@@ -43,6 +44,16 @@ class StudentT(LocScale):
         Prior.__init__(self, shape, df=df, loc=loc, scale=scale)
 
 
+class GenNorm(LocScale):
+    "generalised normal; the shape parameter ``beta`` rides in the hook's ``df`` slot"
+    _dist = GeneralizedNormal
+    fused_kind = FUSED_GENNORM
+    _shape_arg = "beta"
+
+    def __init__(self, shape, loc, scale, beta=0.5):
+        Prior.__init__(self, shape, loc=loc, scale=scale, beta=beta)
+
+
 class Improper(Normal):
     "samples like a Normal, contributes nothing to the log-density"
     fused_kind = FUSED_NONE      # "fused" as a no-op: neither gradient nor log-density
@@ -51,17 +62,25 @@ class Improper(Normal):
         return 0.0
 
 
-_BY_NAME = {"gaussian": Normal, "laplace": Laplace, "student-t": StudentT,
-            "cauchy": Cauchy, "improper": Improper}
+def _table():
+    from . import hierarchical as H
+    return {"gaussian": Normal, "laplace": Laplace, "student-t": StudentT, "cauchy": Cauchy,
+            "improper": Improper, "gennorm": GenNorm,
+            "gaussian_gamma": H.NormalGamma, "gaussian_uniform": H.NormalUniform, "horseshoe": H.Horseshoe,
+            "laplace_gamma": H.LaplaceGamma, "laplace_uniform": H.LaplaceUniform,
+            "student-t_gamma": H.StudentTGamma, "student-t_uniform": H.StudentTUniform,
+            "gennorm_uniform": H.GenNormUniform}
 
 
 def get_prior(name):
-    """Name -> class for the priors on the hot path (reference table:
-    prior/mixture.py:17-50; the remaining names are out of scope)."""
+    """Name -> class for the element-wise and hierarchical-scale priors (reference table:
+    prior/mixture.py:17-50; correlated / data-driven / empirical-Bayes / mixture entries are out of scope,
+    DESIGN.md)."""
     if isinstance(name, type) and issubclass(name, Prior):
         return name
+    table = _table()
     try:
-        return _BY_NAME[name]
+        return table[name]
     except KeyError:
         raise KeyError(f"prior '{name}' is outside the accelerated path; "
-                       f"available: {sorted(_BY_NAME)}") from None
+                       f"available: {sorted(table)}") from None

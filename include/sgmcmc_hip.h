@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 2
+#define SGMCMC_ABI_VERSION 3
 #define SGMCMC_CHUNK 4096 /* default elements per arena chunk = 256 threads x 4 items x 4 elements */
 #define SGMCMC_CHUNK_SMALL 1024 /* small models: one item per thread, 4x more workgroups */
 #define SGMCMC_NSUMS 6
@@ -61,9 +61,21 @@ enum {
                                  fused priors' log-density partials (sgmcmc_grad_reduce_prior):
                                  finish state[s].aux and scalars[2] in the same launch */
 };
-/* element-wise priors the step kernel can differentiate in-flight (prior/loc_scale.py) */
+/* element-wise priors the kernels differentiate in closed form (prior/loc_scale.py, prior/distributions.py:75-79)
+ * and the element-wise hyper-priors of a hierarchical scale (prior/transformed.py:55-87, hierarchical.py:17-104):
+ *   GENNORM            log p = -log(2 scale) - lgamma(1/beta) + log beta - (|theta - loc| / scale)^beta; beta in prior_df
+ *   GAMMA_SOFTPLUS     theta is the raw parameter s, the value x = softplus(s) ~ Gamma(concentration = prior_loc,
+ *                      rate = prior_scale): log p = c log r - lgamma(c) + (c-1) log x - r x
+ *   UNIFORM_CDF        value x = low + (high - low) Phi(s), low = prior_loc, high = prior_scale: log p = -log(high-low)
+ *   HALFCAUCHY_SOFTPLUS value x = softplus(s) * multiplier (prior_loc) ~ HalfCauchy(scale = prior_scale), the density
+ *                      evaluated AT x: log p = log(2 / (pi g)) - log(1 + (x/g)^2)
+ * A weight segment whose scale_link > 0 takes its scale from the VALUE of hyper segment scale_link - 1 (one element)
+ * at launch time instead of prior_scale; sgmcmc_prior_grad then also adds
+ * -(1/N) (d/dscale sum_j log p(theta_j)) dx/ds to the hyper segment's gradient (flags & SGMCMC_PRIOR_HAS_LINKS). */
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
-       SGMCMC_PRIOR_STUDENT_T = 3, SGMCMC_PRIOR_CAUCHY = 4 };
+       SGMCMC_PRIOR_STUDENT_T = 3, SGMCMC_PRIOR_CAUCHY = 4, SGMCMC_PRIOR_GENNORM = 5,
+       SGMCMC_PRIOR_GAMMA_SOFTPLUS = 6, SGMCMC_PRIOR_UNIFORM_CDF = 7, SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS = 8 };
+enum { SGMCMC_PRIOR_HAS_LINKS = 1 }; /* flags of sgmcmc_prior_grad */
 
 /* One parameter tensor.  Device-resident array, written by the host. */
 typedef struct {
@@ -74,7 +86,7 @@ typedef struct {
   int64_t first_chunk;
   int64_t noise_base;   /* Philox element index of element 0 (multiple of 4) */
   int32_t prior_kind;   /* SGMCMC_PRIOR_*; NONE = g already holds the full gradient */
-  int32_t reserved;
+  int32_t scale_link;   /* > 0: the prior's scale is the value of hyper segment scale_link - 1 (see above) */
   double prior_loc, prior_scale, prior_df;
 } sgmcmc_segment;
 
@@ -148,10 +160,10 @@ const char* sgmcmc_error_string(int err);
  * HMC._step_fn (mcmc/hmc.py:41-79). */
 int sgmcmc_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream);
 
-/* As sgmcmc_step, additionally recording ev_start immediately before and ev_stop
- * immediately after the fused update kernel (not the finalize kernel) on `stream`, so a
- * caller can measure that kernel's duration live (bench.py roofline).  Events are
- * hipEvent_t created by sgmcmc_event_create. */
+/* As sgmcmc_step, with the fused update kernel (not the finalize kernel) launched so that ev_start /
+ * ev_stop carry ITS begin / end timestamps (hipExtLaunchKernelGGL): hipEventElapsedTime(ev_start,
+ * ev_stop) is that kernel's execution time, measured live (bench.py roofline).  Events are hipEvent_t
+ * created by sgmcmc_event_create. */
 int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream,
                       void* ev_start, void* ev_stop);
 /* As sgmcmc_step, but the kernels read the transition's scalars from DEVICE memory
@@ -182,6 +194,13 @@ int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A
                                void* stream);
 int sgmcmc_event_create(void** ev);
 int sgmcmc_event_destroy(void* ev);
+/* hipEventRecord on `stream`: lets a caller bracket ANY entry point of this library with events on the
+ * stream its kernels are launched on (bench.py's live roofline timing of the convolution kernels). */
+int sgmcmc_event_record(void* ev, void* stream);
+/* The NEXT kernel this library launches (from the calling thread's next entry-point call) carries the two
+ * events in its dispatch packet, as sgmcmc_step_timed does for the update kernel: the elapsed time between
+ * them is that kernel's own duration.  Used by bench.py to time the convolution kernels live. */
+int sgmcmc_time_next_launch(void* ev_start, void* ev_stop);
 int sgmcmc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
 
 /* m <- sqrt(keep)*m + std*xi   (keep == 0: m <- std*xi).
@@ -206,7 +225,8 @@ int sgmcmc_delta_energy(const sgmcmc_layout* L, int kind, double num_data, doubl
 int sgmcmc_segment_sum(const sgmcmc_layout* L, int which, uint32_t flags, void* stream);
 
 /* g <- g - (1/N) dlog p(theta)/dtheta for every segment with prior_kind != NONE
- * (element-wise Normal / Laplace / Student-t with scalar loc, scale, df), i.e. what
+ * (element-wise Normal / Laplace / Student-t / Cauchy / generalised normal with scalar loc, scale, df / beta,
+ * and the hyper-priors of hierarchical scales; see SGMCMC_PRIOR_*), i.e. what
  * autograd adds for the "- log_prior / N" term of potential_avg (models/base.py:72-77,
  * prior/base.py:57-58, prior/loc_scale.py:34-35,66-67,74-77).  With calc_log_prob != 0 also
  * state[s].aux <- sum_j log p(theta_j) (fp64) and scalars[2] <- the total over segments.
@@ -429,13 +449,16 @@ int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const floa
 /* Minibatch gather from an HBM-resident image set with random crop (zero padding `pad`) and horizontal flip
  * applied on the way -- the `cifar10_augmented` pipeline (data/CIFAR/cifar.py:136-172: RandomCrop(32,
  * padding=4), RandomHorizontalFlip) without leaving the device:
- *   out[b,c,y,x] = data[idx[b], c, y + dy - pad, x' + dx - pad] (0 outside), x' = flip_b ? W-1-x : x,
+ *   out[b,c,y,x] = data[idx[b], c, y + dy - pad, x' + dx - pad] (fill[c] outside; fill == NULL: 0),
+ *   x' = flip_b ? W-1-x : x,
  *   (dx, dy, flip_b) = Philox4x32-10(seed; counter (idx[b], draw, purpose 3, stream)) -> r0 % (2 pad + 1),
  *   r1 % (2 pad + 1), r2 & 1 (only if `flip`).  `idx`: int64 device array of data-set rows; `draw`: the
- *   caller's per-pass counter.  pad = 0 and flip = 0 is a plain gather. */
-int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, int batch, int channels,
-                          int height, int width, int pad, int flip, uint64_t seed, uint32_t stream,
-                          uint64_t draw, void* stream_);
+ *   caller's per-pass counter.  pad = 0 and flip = 0 is a plain gather.  `fill` (device, [channels], or NULL):
+ *   the value of the padding -- the reference pads the RAW image with black before normalising, so on
+ *   normalised data the padding of channel c is (0 - mean_c) / std_c. */
+int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, const float* fill, int batch,
+                          int channels, int height, int width, int pad, int flip, uint64_t seed,
+                          uint32_t stream, uint64_t draw, void* stream_);
 
 /* loss = scale * sum_b -log softmax(logits_b)[y_b] for up to 1024 rows of up to 16 classes (the likelihood term of
  * models/base.py:168-191), one launch each way: forward keeps probs [rows][classes] for the backward,

@@ -29,8 +29,8 @@ def decisions(rows, seed, stream, draw, pad, flip):
     return dx, dy, fl
 
 
-def gather(data, rows, seed, stream, draw, pad, flip):
-    "data [N, C, H, W] -> augmented batch [len(rows), C, H, W]"
+def gather(data, rows, seed, stream, draw, pad, flip, fill=None):
+    "data [N, C, H, W] -> augmented batch [len(rows), C, H, W]; ``fill``: per-channel padding value (default 0)"
     data = np.asarray(data)
     n, c, h, w = data.shape
     dx, dy, fl = decisions(rows, seed, stream, draw, pad, flip)
@@ -41,5 +41,5 @@ def gather(data, rows, seed, stream, draw, pad, flip):
         sy = ys + dy[b]
         ok = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h)
         src = data[int(row)][:, np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1)]
-        out[b] = np.where(ok[None], src, 0)
+        out[b] = np.where(ok[None], src, 0 if fill is None else np.asarray(fill, dtype=data.dtype)[:, None, None])
     return out

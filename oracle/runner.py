@@ -25,6 +25,7 @@ def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metr
         raise ValueError("Potential is NaN")
     store = (step % metrics_skip) == 0
     opt.step(calc_metrics=store)
+    de = None
     if store:
         de = opt.delta_energy(initial_potential, potential)
         _ = (loss.item(), log_prior.item(), potential.item(), accs.mean().item(), de)
@@ -32,6 +33,7 @@ def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metr
             st = opt.state[p]
             _ = (st["preconditioner"], st["est_temperature"], st["est_config_temp"])
     scheduler.step()
+    return dict(potential=potential, delta_energy=de)     # (tensors: no extra read-back in the timed loop)
 
 
 def _setup(make_model, batches, num_data, lr, momentum, temperature, steps_per_cycle):
@@ -64,7 +66,7 @@ def _timed_loop(model, opt, sched, batches, num_data, step, budget_s, min_steps)
 
 
 def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperature, steps_per_cycle,
-                      budget_s=12.0, warmup=5, min_steps=20, thread_choices=(1, 2, 4, 8, 16, 32, 64)):
+                      budget_s=12.0, warmup=5, min_steps=20, thread_choices=(1, 2, 4, 8, 16, 32, 64, 128)):
     """Run the loop above on the host for about ``budget_s`` seconds with the thread count
     that is fastest for this workload (a short calibration over ``thread_choices`` first:
     tiny nets get SLOWER with more OpenMP threads, and the baseline must not be handicapped).

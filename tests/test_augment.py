@@ -45,6 +45,10 @@ def test_kernel_matches_oracle_bit_for_bit(shape, pad, flip):
         got = aug.gather(data.cuda(), idx.cuda(), draw).cpu().numpy()
         want = ref.gather(data.numpy(), idx.numpy(), aug.seed, aug.stream, draw, pad, flip)
         assert np.array_equal(got, want)
+    fill = [0.5 - c for c in range(shape[1])]             # the reference's border on normalised data: -mean/std
+    filled = augment.RandomCropFlip(pad=pad, flip=flip, seed=7, stream=1, fill=fill)
+    assert np.array_equal(filled.gather(data.cuda(), idx.cuda(), 3).cpu().numpy(),
+                          ref.gather(data.numpy(), idx.numpy(), 7, 1, 3, pad, flip, fill=fill))
     assert aug.gather(data.cuda(), idx[:0].cuda(), 0).shape == (0,) + shape[1:]
     with pytest.raises(ValueError):
         aug.gather(data, idx, 0)                      # CPU tensor: no fallback
@@ -106,3 +110,45 @@ def test_reject_runner_runs_on_an_augmented_set():
     _, loss = metrics.column("loss")
     assert np.isfinite(loss[~np.isnan(loss)]).all()
     assert runner.get_samples()["net.module.0.weight_prior.p"].shape[0] == 1
+
+
+@pytest.mark.gpu
+def test_kernel_output_obeys_the_reference_pipelines_contract():
+    """The reference augments with torchvision's RandomCrop(32, padding=4) + RandomHorizontalFlip()
+    (bnn_priors/data/CIFAR/cifar.py:136-172): every output is a 32x32 window of the ZERO-padded (4 pixels
+    per side) image at an offset uniform over {0..8}^2, mirrored with probability 1/2, independently per
+    image and per traversal.  torchvision's random stream cannot be replayed, so the contract is checked on
+    the HIP kernel's OUTPUT itself -- by exhaustive search over the 81 x 2 candidate windows built with
+    plain torch ops, not through the numpy restatement of the kernel."""
+    g = torch.Generator().manual_seed(12)
+    n = 4000
+    data = torch.randn(n, 3, 32, 32, generator=g)
+    padded = torch.nn.functional.pad(data, (4, 4, 4, 4))                     # zero padding, as RandomCrop's default fill
+    aug = augment.RandomCropFlip(pad=4, flip=True, seed=2024, stream=0)
+    idx = torch.arange(n)
+    seen = []
+    for draw in (0, 1):
+        out = aug.gather(data.cuda(), idx.cuda(), draw).cpu()
+        found = torch.full((n, 3), -1, dtype=torch.int64)
+        for oy in range(9):
+            for ox in range(9):
+                win = padded[:, :, oy:oy + 32, ox:ox + 32]
+                for fl, cand in ((0, win), (1, win.flip(-1))):
+                    hit = (cand == out).flatten(1).all(1) & (found[:, 0] < 0)
+                    found[hit] = torch.tensor([ox, oy, fl])
+        assert (found[:, 0] >= 0).all()                      # every output IS such a window
+        ox, oy, fl = found[:, 0].numpy(), found[:, 1].numpy(), found[:, 2].numpy()
+        counts = np.bincount(ox * 9 + oy, minlength=81)
+        expect = n / 81
+        assert counts.min() > 0.55 * expect and counts.max() < 1.5 * expect
+        chi2 = ((counts - expect) ** 2 / expect).sum()       # 80 degrees of freedom: mean 80, sd 12.6
+        assert chi2 < 80 + 5 * 12.65
+        assert abs(fl.mean() - 0.5) < 4 * 0.5 / n ** .5
+        assert abs(np.corrcoef(ox, oy)[0, 1]) < 0.06 and abs(np.corrcoef(ox, fl)[0, 1]) < 0.06
+        seen.append(found)
+    same = (seen[0] == seen[1]).all(1).float().mean().item()
+    assert same < 3.0 / 162                                   # a new traversal draws new windows
+    other = augment.RandomCropFlip(pad=4, flip=True, seed=2024, stream=1)       # another chain
+    out_b = other.gather(data.cuda(), idx.cuda(), 0).cpu()
+    out_a = aug.gather(data.cuda(), idx.cuda(), 0).cpu()
+    assert (out_a == out_b).flatten(1).all(1).float().mean().item() < 3.0 / 162

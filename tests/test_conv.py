@@ -271,3 +271,67 @@ def test_first_layer_convolution_matches_float64_reference(n):
     assert torch.equal(w2.grad, wg.grad)
     conv.conv_first(x, w2).backward(dy)
     assert torch.equal(w2.grad, wg.grad + wg.grad) and not conv._pending
+
+
+# ------------------------------------------------------------------ deferred weight-gradient reduction
+def _conv_mod():
+    from bnn_priors_amd import conv
+    return conv
+
+
+@pytest.mark.gpu
+def test_weight_gradient_is_reduced_immediately_outside_the_samplers_own_pass():
+    "user code calling the operator directly never sees an unreduced gradient (no deferring() scope)"
+    conv = _conv_mod()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 16, 32, 32, generator=g).cuda().requires_grad_()
+    w = torch.randn(16, 16, 3, 3, generator=g).cuda().requires_grad_()
+    seen = {}
+    w.register_hook(lambda gr: seen.setdefault("dw", gr.clone()))     # reads the gradient DURING backward
+    conv.conv3x3(x, w).square().sum().backward()
+    assert not conv._pending
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    torch.nn.functional.conv2d(xr, wr, None, 1, 1).square().sum().backward()
+    torch.testing.assert_close(seen["dw"], wr.grad, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(w.grad, wr.grad, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_deferring_scope_handles_shared_weights_and_existing_grads():
+    """inside deferring(): a weight used by two operations (gradients summed mid-backward) and a weight that
+    already has a .grad both take the immediate route; a weight used once is deferred -- all three correct"""
+    conv = _conv_mod()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 16, 32, 32, generator=g).cuda()
+    ws = [torch.randn(16, 16, 3, 3, generator=g).cuda().mul_(0.1).requires_grad_() for _ in range(3)]
+    ws[2].grad = torch.ones_like(ws[2])
+    with conv.deferring():
+        h = conv.conv3x3(conv.conv3x3(x, ws[0]), ws[0])          # shared
+        h = conv.conv3x3(conv.conv3x3(h, ws[1]), ws[2])          # once / has grad
+        h.square().mean().backward()
+    assert not conv._pending and not conv._defer["active"]
+    rs = [w.detach().clone().requires_grad_() for w in ws]
+    rs[2].grad = torch.ones_like(rs[2])
+    F = torch.nn.functional
+    h = F.conv2d(F.conv2d(x, rs[0], None, 1, 1), rs[0], None, 1, 1)
+    h = F.conv2d(F.conv2d(h, rs[1], None, 1, 1), rs[2], None, 1, 1)
+    h.square().mean().backward()
+    for w, r in zip(ws, rs):
+        torch.testing.assert_close(w.grad, r.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_deferring_scope_recovers_after_an_exception():
+    conv = _conv_mod()
+    x = torch.randn(2, 16, 32, 32).cuda()
+    w = torch.randn(16, 16, 3, 3).cuda().requires_grad_()
+    with pytest.raises(RuntimeError, match="boom"):
+        with conv.deferring():
+            y = conv.conv3x3(x, w)
+            raise RuntimeError("boom")
+    assert not conv._defer["active"] and not conv._pending
+    with conv.deferring():
+        conv.conv3x3(x, w).sum().backward()
+    ref = w.detach().clone().requires_grad_()
+    torch.nn.functional.conv2d(x, ref, None, 1, 1).sum().backward()
+    torch.testing.assert_close(w.grad, ref.grad, rtol=2e-4, atol=2e-3)

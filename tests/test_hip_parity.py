@@ -350,3 +350,89 @@ def test_channels_last_parameters_are_supported():
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert torch.equal(a, b)            # HMC draws no noise: layouts must agree bit for bit
     assert outs[0][3] == pytest.approx(outs[1][3], rel=1e-12)
+
+
+# ------------------------------------------------------------------ round-2 additions
+@pytest.mark.parametrize("small", [True, False])
+def test_tensor_without_gradient_is_left_untouched(small):
+    """raise_on_no_grad=False: the reference skips tensors whose grad is None -- parameter, momentum, noise,
+    square_avg and the running scalars all stay (mcmc/sgld.py:96-100); the others step as if alone."""
+    from oracle.noise import NoiseSource
+    from oracle.samplers import RefVerletSGLD
+    mcmc = _mcmc()
+    g = torch.Generator().manual_seed(21)
+    numels = [700, 33, 5000]
+    cpu = [torch.nn.Parameter(torch.randn(n, generator=g)) for n in numels]
+    dev = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in cpu]
+    ref = RefVerletSGLD(cpu, lr=0.01, num_data=11, momentum=0.7, temperature=1.0, raise_on_no_grad=False,
+                        noise=NoiseSource(5, numels, stream=0))
+    hip = mcmc.VerletSGLD(dev, lr=0.01, num_data=11, momentum=0.7, temperature=1.0, raise_on_no_grad=False,
+                          seed=5, chain_id=0, small_finalize=small)
+    ref.sample_momentum()
+    hip.sample_momentum()
+    frozen = 1
+    for call in ("initial_step", "step", "step"):
+        for i, (p, q) in enumerate(zip(cpu, dev)):
+            p.grad = None if i == frozen else torch.randn(p.shape, generator=g)
+            q.grad = None if i == frozen else p.grad.to(DEV)
+        th0 = dev[frozen].detach().clone()
+        m0 = hip.state[dev[frozen]]['momentum_buffer'].clone()
+        v0 = hip.state[dev[frozen]]['square_avg'].clone()
+        getattr(ref, call)()
+        getattr(hip, call)()
+        assert dev[frozen].grad is None                      # no gradient is fabricated
+        assert torch.equal(dev[frozen].detach(), th0)
+        assert torch.equal(hip.state[dev[frozen]]['momentum_buffer'], m0)
+        assert torch.equal(hip.state[dev[frozen]]['square_avg'], v0)
+        for i, (p, q) in enumerate(zip(cpu, dev)):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+            torch.testing.assert_close(hip.state[q]['momentum_buffer'].cpu(), ref.state[p]['momentum_buffer'],
+                                       rtol=2e-6, atol=2e-7)
+            if i != frozen:
+                for k in ("delta_energy", "est_temperature", "est_config_temp"):
+                    assert hip.state[q][k] == pytest.approx(ref.state[p][k], rel=2e-5, abs=1e-6), (call, k)
+
+
+def test_state_dict_round_trip_continues_the_chain_bit_for_bit():
+    "optimizer.state_dict() / load_state_dict(): arenas, device-resident scalars and the Philox position survive"
+    mcmc = _mcmc()
+
+    def make():
+        g = torch.Generator().manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(n, generator=g).to(DEV)) for n in (1500, 40, 4100)]
+        return ps, mcmc.VerletSGLD(ps, lr=0.01, num_data=50, momentum=0.9, temperature=1.0, seed=77, chain_id=3)
+
+    def grads(ps, k):
+        g = torch.Generator().manual_seed(100 + k)
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g).to(DEV)
+
+    pa, a = make()
+    a.sample_momentum()
+    for k, call in enumerate(("initial_step", "step", "step")):
+        grads(pa, k)
+        getattr(a, call)()
+    a.update_preconditioner()
+    sd = a.state_dict()
+    theta = [p.detach().clone() for p in pa]
+    pb, b = make()
+    with torch.no_grad():
+        for p, t in zip(pb, theta):
+            p.copy_(t)
+    b.load_state_dict(sd)
+    for p, q in zip(pa, pb):
+        for key in ("delta_energy", "prev_new_momentum_delta", "est_temperature", "est_config_temp", "preconditioner"):
+            assert a.state[p][key] == b.state[q][key], key
+        assert b.state[q]['momentum_buffer'].data_ptr() == b.engine.momentum_view(b.engine.index[id(q)]).data_ptr()
+    for k, call in enumerate(("step", "step", "final_step")):
+        grads(pa, 10 + k)
+        grads(pb, 10 + k)
+        getattr(a, call)()
+        getattr(b, call)()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p.detach(), q.detach())
+        assert torch.equal(a.state[p]['momentum_buffer'], b.state[q]['momentum_buffer'])
+        assert torch.equal(a.state[p]['square_avg'], b.state[q]['square_avg'])
+        assert a.state[p]['delta_energy'] == b.state[q]['delta_energy']
+    assert a.delta_energy(0.2, 0.1) == b.delta_energy(0.2, 0.1)
+    assert a.engine.mh_uniform() == b.engine.mh_uniform()

@@ -75,3 +75,101 @@ def test_fused_prior_kernel_matches_autograd(dtype):
         assert per_seg[4] == 0.0 and per_seg[5] == 0.0
     finally:
         torch.set_default_dtype(old)
+
+
+# ------------------------------------------------------------------ fixtures from the imported reference
+def _prior_cases(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "priors.npz"))
+    keys = sorted({k.rsplit("|", 1)[0] for k in z.files})
+    return z, keys
+
+
+def _build(name, extra, shape, loc, scale, dtype):
+    kw = {}
+    for item in filter(None, extra.split("_")):
+        for field in ("hyperscale", "rate", "beta", "df"):
+            if item.startswith(field):
+                kw[field] = float(item[len(field):])
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        torch.manual_seed(0)
+        return P.get_prior(name)(shape, loc, scale, **kw)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _load_case(z, key):
+    name, extra, shape, loc, scale, dt = key.split("|")
+    dtype = torch.float32 if dt == "float32" else torch.float64
+    pr = _build(name, extra, tuple(int(s) for s in shape.split("x")), float(loc), float(scale), dtype)
+    with torch.no_grad():
+        pr.p.copy_(torch.from_numpy(z[key + "|theta"]).to(dtype))
+        hyper = pr.scale_link() or (getattr(pr, "beta", None) if isinstance(getattr(pr, "beta", None), P.Prior) else None)
+        if hyper is not None:
+            hyper.p.fill_(float(z[key + "|hyper_p"]))
+    return pr, hyper, dtype
+
+
+def test_prior_modules_match_reference_fixtures(golden_dir):
+    """log_prob and its gradient of every prior family of the hot path against values captured from the
+    imported reference (tests/golden/make_prior_goldens.py; prior/loc_scale.py:34-96,
+    hierarchical.py:17-104, transformed.py:55-87): pins the autograd formulation of the product's modules"""
+    z, keys = _prior_cases(golden_dir)
+    assert len(keys) == 96
+    for key in keys:
+        pr, hyper, dtype = _load_case(z, key)
+        tol = dict(rel=2e-5, abs=2e-5) if dtype == torch.float32 else dict(rel=1e-11, abs=1e-11)
+        lps = [m.log_prob() for _, m in P.named_priors(pr)]
+        assert float(lps[0]) == pytest.approx(float(z[key + "|log_prob"]), **tol), key
+        total = sum(lps)
+        want = torch.from_numpy(z[key + "|grad_theta"]).to(dtype)
+        if isinstance(total, torch.Tensor) and total.requires_grad:
+            total.backward()
+            got = pr.p.grad if pr.p.grad is not None else torch.zeros_like(pr.p)
+        else:
+            got = torch.zeros_like(pr.p)
+        torch.testing.assert_close(got, want, rtol=tol["rel"] * 5, atol=tol["abs"])
+        if hyper is not None:
+            assert float(hyper()) == pytest.approx(float(z[key + "|hyper_value"]), **tol), key
+            assert float(lps[1]) == pytest.approx(float(z[key + "|hyper_log_prob"]), **tol), key
+            g = 0.0 if hyper.p.grad is None else float(hyper.p.grad)
+            assert g == pytest.approx(float(z[key + "|grad_hyper"]), rel=tol["rel"] * 20, abs=tol["abs"] * 20), key
+
+
+@pytest.mark.gpu
+def test_fused_prior_hook_matches_reference_fixtures(golden_dir):
+    """the HIP prior hook (sgmcmc_prior_grad: closed-form gradient of -log p / N into g, log-density in fp64,
+    chain-rule term of hierarchical scales) against the reference's values for every fusable case"""
+    from bnn_priors_amd import mcmc
+    z, keys = _prior_cases(golden_dir)
+    dev, N, seen = "cuda:0", 77.0, set()
+    for key in keys:
+        pr, hyper, dtype = _load_case(z, key)
+        name = key.split("|")[0]
+        pr = pr.to(dev)
+        hyper = pr.scale_link()
+        params = [pr.p] + ([hyper.p] if hyper is not None else [])
+        opt = mcmc.VerletSGLD(params, lr=0.01, num_data=N, momentum=0.9)
+        leftover = opt.fuse_priors(pr)
+        if name == "gennorm_uniform":
+            assert leftover                     # the shape parameter's hyper-prior stays in autograd
+            continue
+        assert not leftover, key
+        seen.add(name)
+        g0 = torch.randn(pr.p.shape, generator=torch.Generator().manual_seed(5)).to(dtype).to(dev)
+        pr.p.grad = g0.clone()
+        opt.add_prior_gradient(calc_log_prior=True)
+        tol = dict(rtol=1e-4, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-10, atol=1e-12)
+        want = g0 - torch.from_numpy(z[key + "|grad_theta"]).to(dtype).to(dev) / N
+        torch.testing.assert_close(pr.p.grad, want, **tol)
+        lp_want = float(z[key + "|log_prob"]) if name != "improper" else 0.0
+        if hyper is not None:
+            lp_want += float(z[key + "|hyper_log_prob"])
+            g_h = -float(z[key + "|grad_hyper"]) / N
+            assert float(hyper.p.grad) == pytest.approx(g_h, rel=tol["rtol"] * 5, abs=tol["atol"] * 5), key
+        assert opt.fused_log_prior().item() == pytest.approx(lp_want, rel=1e-5 if dtype == torch.float32 else 1e-11,
+                                                             abs=1e-4 if dtype == torch.float32 else 1e-10), key
+    assert {"gaussian", "laplace", "student-t", "cauchy", "gennorm", "gaussian_gamma", "laplace_gamma",
+            "student-t_gamma", "gaussian_uniform", "laplace_uniform", "student-t_uniform", "horseshoe"} <= seen
