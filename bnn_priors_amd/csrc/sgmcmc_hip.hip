@@ -624,11 +624,16 @@ __device__ __forceinline__ int64_t seg_chunks(const sgmcmc_layout& L, const sgmc
 // Scalar bookkeeping of one segment after its six sums S are known (thread-serial).
 // Returns the segment's contribution to delta_energy's loop: state.delta_energy + point energy
 // evaluated with THIS transition's gradient / momentum (verlet_sgld.py:32-47, hmc.py:32-33).
+// `pre` (optional): {delta_energy, prev_delta, point_energy} of the segment loaded EARLIER by the caller, so
+// that those loads overlap the reduction of the chunk partials instead of following it.
 __device__ __forceinline__ double segment_bookkeeping(const sgmcmc_layout& L, const sgmcmc_step_args& A,
                                                       int seg, const sgmcmc_segment& s,
-                                                      const double (&S)[SGMCMC_NSUMS]) {
+                                                      const double (&S)[SGMCMC_NSUMS],
+                                                      const double* pre = nullptr) {
   sgmcmc_seg_state* st = &L.state[seg];
-  if (s.g == nullptr) return st->delta_energy + st->point_energy;  // skipped tensor: state untouched
+  if (s.g == nullptr)   // skipped tensor: state untouched
+    return pre ? pre[0] + pre[2] : st->delta_energy + st->point_energy;
+  if (pre) { st->delta_energy = pre[0]; st->prev_delta = pre[1]; }   // (same values: keeps the code below one path)
 #pragma unroll
   for (int k = 0; k < SGMCMC_NSUMS; ++k) st->sums[k] = S[k];
   const double d = (double)s.numel, M = s.M;
@@ -736,8 +741,83 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
   }
 }
 
+// The same bookkeeping over SEVERAL workgroups, for nets with many tensors (googleresnet: 65): a wave per
+// segment, all segments in flight at once (one round of dependent loads instead of 65 / 64 groups x 2 rounds in
+// a single workgroup), and the segment-ordered energy total by the LAST workgroup to arrive.  Hand-off without
+// fences: every wave publishes its segments' energy terms with agent-scope (write-through) 8-byte stores into
+// the spare slot partials[first_chunk][7], drains them (s_waitcnt vmcnt(0)), the workgroup takes a ticket with
+// a device-scope atomic; the workgroup that draws the last ticket reads the terms back with agent-scope loads
+// (MI355X_MICROARCH.md "Valid forms": 8-byte agent atomics on both sides) and resets the ticket.
+__device__ __forceinline__ void finalize_multi_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)blockDim.x >> 6;
+  const int gw = (int)blockIdx.x * wpb + wave, n_w = (int)gridDim.x * wpb;
+  for (int seg = A.seg_begin + gw; seg < A.seg_end; seg += n_w) {
+    const sgmcmc_segment s = L.segs[seg];
+    double pre[3] = {0.0, 0.0, 0.0};
+    if (lane == 0) {
+      const sgmcmc_seg_state* st = &L.state[seg];
+      pre[0] = st->delta_energy; pre[1] = st->prev_delta; pre[2] = st->point_energy;
+    }
+    const int64_t n = seg_chunks(L, s);
+    double S[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
+    for (int64_t c = lane; c < n; c += 64) {
+      const double* __restrict__ q = L.partials + (s.first_chunk + c) * SGMCMC_PSTRIDE;
+#pragma unroll
+      for (int k = 0; k < SGMCMC_NSUMS; ++k) S[k] += q[k];
+    }
+#pragma unroll
+    for (int k = 0; k < SGMCMC_NSUMS; ++k) {
+      double x = S[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      S[k] = x;
+    }
+    if (lane == 0) {
+      const double e = segment_bookkeeping(L, A, seg, s, S, pre);
+      __hip_atomic_store(L.partials + s.first_chunk * SGMCMC_PSTRIDE + 7, e, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's published terms have left the CU
+  __shared__ int is_last;
+  __shared__ double terms[kThreads];
+  __syncthreads();
+  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(L.scalars + 7);
+  if (threadIdx.x == 0) {
+    const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t + 1 == (unsigned long long)gridDim.x);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const int n_segs = A.seg_end - A.seg_begin;
+  double total = 0.0;   // segment order, as the reference's Python loop (verlet_sgld.py:32-38)
+  for (int base = 0; base < n_segs; base += (int)blockDim.x) {
+    const int i = base + (int)threadIdx.x;
+    if (i < n_segs)
+      terms[threadIdx.x] = __hip_atomic_load(L.partials + L.segs[A.seg_begin + i].first_chunk * SGMCMC_PSTRIDE + 7,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = n_segs - base < (int)blockDim.x ? n_segs - base : (int)blockDim.x;
+      for (int j = 0; j < m; ++j) total += terms[j];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    L.scalars[3] = total;
+    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
   finalize_step_body(L, A);
+}
+__global__ __launch_bounds__(kThreads) void finalize_multi_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
+  finalize_multi_body(L, A);
+}
+__global__ __launch_bounds__(kThreads) void finalize_multi_kernel_indirect(sgmcmc_layout L,
+                                                                           const sgmcmc_step_args* Ap) {
+  const sgmcmc_step_args A = *Ap;
+  finalize_multi_body(L, A);
 }
 __global__ __launch_bounds__(kThreads) void finalize_step_kernel_indirect(sgmcmc_layout L,
                                                                           const sgmcmc_step_args* Ap) {
@@ -1010,10 +1090,18 @@ void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sg
                      hipStream_t s) {
   if (A->flags & SGMCMC_DEFER_FINALIZE) return;  // the caller runs it later (sgmcmc_finalize)
   const bool small = A->flags & SGMCMC_SMALL_FINALIZE;
+  const int n_segs = A->seg_end - A->seg_begin;
+  // many tensors and no log-prior to finish: a wave per segment over several workgroups, last arriver totals
+  // (A_host carries the same SMALL_FINALIZE / WITH_LOG_PRIOR bits as the device copy: they select kernels)
+  if (small && n_segs > 8 && !(A->flags & SGMCMC_WITH_LOG_PRIOR)) {
+    const dim3 grid((unsigned)((n_segs + 3) / 4)), block(kThreads);
+    if (Ad) SGMCMC_LAUNCH(finalize_multi_kernel_indirect, grid, block, 0, s, *L, Ad);
+    else SGMCMC_LAUNCH(finalize_multi_kernel, grid, block, 0, s, *L, *A);
+    return;
+  }
   // small: one workgroup, one wave per segment in flight -- 16 waves once there are more than 4 segments
   // (every segment costs a chain of dependent loads, so the round count is what matters)
-  const dim3 grid(small ? 1u : (unsigned)(A->seg_end - A->seg_begin)),
-      block(small && A->seg_end - A->seg_begin > 4 ? 1024u : (unsigned)kThreads);
+  const dim3 grid(small ? 1u : (unsigned)n_segs), block(small && n_segs > 4 ? 1024u : (unsigned)kThreads);
   if (Ad) {
     if (small) SGMCMC_LAUNCH(finalize_small_kernel_indirect, grid, block, 0, s, *L, Ad);
     else SGMCMC_LAUNCH(finalize_step_kernel_indirect, grid, block, 0, s, *L, Ad);
