@@ -32,7 +32,7 @@ WITH_LOG_PRIOR = 128
 DEFER_FINALIZE = 256
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T, PRIOR_CAUCHY, PRIOR_GENNORM = 0, 1, 2, 3, 4, 5
 PRIOR_GAMMA_SOFTPLUS, PRIOR_UNIFORM_CDF, PRIOR_HALFCAUCHY_SOFTPLUS = 6, 7, 8
-PRIOR_HAS_LINKS = 1
+PRIOR_HAS_LINKS, PRIOR_FULL = 1, 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
@@ -74,6 +74,13 @@ class ReduceJob(ctypes.Structure):
     "sgmcmc_reduce_job"
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_slabs", ctypes.c_int32),
                 ("numel", ctypes.c_int32)]
+
+
+class BlockBwdArgs(ctypes.Structure):
+    "sgmcmc_block_bwd_args"
+    _fields_ = [(name, ctypes.c_void_p) for name in (
+        "dz", "mask_out", "y", "coef", "bcoef", "xcoef", "ye", "ecoef", "egamma", "esums", "ebcoef", "edgamma",
+        "edbeta", "e_dout", "e_out", "ticket")]
 
 
 class GradParts(ctypes.Structure):
@@ -182,6 +189,13 @@ EXPORTS = {
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
+    "sgmcmc_block_conv_fwd": (ctypes.c_int, [ctypes.c_void_p] * 10 + [ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+                              + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "sgmcmc_block_apply": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "sgmcmc_block_sums_doubles": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "sgmcmc_block_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 10 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "sgmcmc_block_conv_bwd": (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.POINTER(BlockBwdArgs)]
+                              + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_first_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
     "sgmcmc_conv_first_wrw": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),

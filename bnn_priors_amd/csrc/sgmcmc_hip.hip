@@ -296,7 +296,8 @@ struct GradParts {
 __device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s, double scale);  // defined with the prior kernels
 
 // value x of a hierarchical scale given the raw hyper-parameter s (see SGMCMC_PRIOR_* in the header) and dx/ds
-__device__ __forceinline__ double hyper_value(const sgmcmc_segment& h, double s, double& dxds) {
+// (out of line: rare path with heavy double-precision math; inlined it costs every caller ~80 VGPRs)
+__device__ __attribute__((noinline)) double hyper_value(const sgmcmc_segment& h, double s, double& dxds) {
   const double sig = 1.0 / (1.0 + exp(-s)), sp = s > 30.0 ? s : log1p(exp(s));
   if (h.prior_kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) { dxds = sig; return sp; }
   if (h.prior_kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) { dxds = sig * h.prior_loc; return sp * h.prior_loc; }
@@ -304,6 +305,24 @@ __device__ __forceinline__ double hyper_value(const sgmcmc_segment& h, double s,
   const double w = h.prior_scale - h.prior_loc;
   dxds = w * 0.3989422804014326779 * exp(-0.5 * s * s);
   return h.prior_loc + w * 0.5 * erfc(-s * 0.7071067811865475244);
+}
+
+__device__ __attribute__((noinline)) double pow_noinline(double a, double b) { return pow(a, b); }
+
+// d log p / ds and log p (normalised) of a hyper-prior kind at raw parameter s; loc / scale as in the header
+__device__ __attribute__((noinline)) double hyper_prior_dlogp(int kind, double loc, double scale, double s, double& l) {
+  const double sig = 1.0 / (1.0 + exp(-s)), x = s > 30.0 ? s : log1p(exp(s));
+  if (kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) {             // loc = concentration, scale = rate
+    l = loc * log(scale) - lgamma(loc) + (loc - 1.0) * log(x) - scale * x;
+    return ((loc - 1.0) / x - scale) * sig;
+  }
+  if (kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) {        // loc = multiplier, scale = gamma
+    const double z = x * loc / scale;
+    l = log(2.0 / (3.14159265358979323846 * scale)) - log1p(z * z);
+    return -2.0 * z / (1.0 + z * z) * (loc / scale) * sig;
+  }
+  l = -log(scale - loc);                                 // UNIFORM_CDF: constant density
+  return 0.0;
 }
 
 template <typename T>
@@ -329,12 +348,13 @@ struct PriorCoef {
   bool linked;
   double loc, scale, df;
   T locT, c_normal, c_laplace, c_t_num, c_t_den, c_gn, inv_scaleT, beta_m1;
+  template <bool FULL = true>
   __device__ __forceinline__ void init(const sgmcmc_layout& L, const sgmcmc_segment* sp, double num_data) {
     kind = sp->prior_kind;
     loc = sp->prior_loc;
     double dxds;
-    linked = sp->scale_link > 0;
-    scale = linked_scale<T>(L, sp, dxds);
+    linked = FULL && sp->scale_link > 0;
+    scale = FULL ? linked_scale<T>(L, sp, dxds) : sp->prior_scale;
     df = kind == SGMCMC_PRIOR_CAUCHY ? 1.0 : sp->prior_df;
     locT = (T)loc;
     c_normal = (T)(1.0 / (scale * scale * num_data));
@@ -353,18 +373,8 @@ struct PriorCoef {
     if (kind == SGMCMC_PRIOR_NONE) return g;
     if (FULL && kind >= SGMCMC_PRIOR_GAMMA_SOFTPLUS) {
       // hyper-priors: th is the raw parameter s; everything in double (one element per tensor)
-      const double s = (double)th, sig = 1.0 / (1.0 + exp(-s)), x = s > 30.0 ? s : log1p(exp(s));
-      double dlp = 0.0, l = 0.0;                      // d log p / ds ; log p (normalised)
-      if (kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) {      // loc = concentration, scale = rate
-        dlp = ((loc - 1.0) / x - scale) * sig;
-        l = loc * log(scale) - lgamma(loc) + (loc - 1.0) * log(x) - scale * x;
-      } else if (kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) {   // loc = multiplier, scale = gamma
-        const double z = x * loc / scale;
-        dlp = -2.0 * z / (1.0 + z * z) * (loc / scale) * sig;
-        l = log(2.0 / (3.14159265358979323846 * scale)) - log1p(z * z);
-      } else {                                        // UNIFORM_CDF: constant density
-        l = -log(scale - loc);
-      }
+      double l;
+      const double dlp = hyper_prior_dlogp(kind, loc, scale, (double)th, l);
       if (calc_logp) lp += l;
       return (T)((double)g - dlp * c_hyper);
     }
@@ -377,7 +387,7 @@ struct PriorCoef {
     } else if (FULL && kind == SGMCMC_PRIOR_GENNORM) {
       const T sgn = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
       const T z = (d < T(0) ? -d : d) * inv_scaleT;
-      g = fma_t<T>(sgn * (T)pow((double)z, (double)beta_m1), c_gn, g);
+      g = fma_t<T>(sgn * (T)pow_noinline((double)z, (double)beta_m1), c_gn, g);
     } else {  // Student-t (df) and Cauchy (= Student-t with df = 1, set by PriorCoef::init)
       g = fma_t<T>(d, c_t_num / fma_t<T>(d, d, c_t_den), g);
     }
@@ -385,7 +395,7 @@ struct PriorCoef {
       const double dd = (double)th - loc, z = dd / scale;
       if (kind == SGMCMC_PRIOR_NORMAL) { lp += -0.5 * z * z; dls += (z * z - 1.0) / scale; }
       else if (kind == SGMCMC_PRIOR_LAPLACE) { lp += -fabs(z); dls += (fabs(z) - 1.0) / scale; }
-      else if (FULL && kind == SGMCMC_PRIOR_GENNORM) lp += -pow(fabs(z), df);
+      else if (FULL && kind == SGMCMC_PRIOR_GENNORM) lp += -pow_noinline(fabs(z), df);
       else { lp += -0.5 * (df + 1.0) * log1p(z * z / df); dls += ((df + 1.0) * z * z / (df + z * z) - 1.0) / scale; }
     }
     return g;
@@ -466,7 +476,7 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
   const float* __restrict__ pp = PARTS ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
   PriorCoef<T> PC;
-  if (PARTS) PC.init(L, sp, G.num_data);
+  if (PARTS) PC.template init<false>(L, sp, G.num_data);
   double dls_unused = 0.0;
 
   double acc[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
@@ -718,7 +728,7 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
       const double e = segment_bookkeeping(L, A, seg, s, S6);
       double lp = 0.0;
       if (with_lp)
-        L.state[seg].aux = lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s, current_scale(L, s));
+        L.state[seg].aux = lp = s.prior_kind == SGMCMC_PRIOR_NONE ? 0.0 : S[6] + (double)s.numel * prior_log_norm(s, s.prior_scale);   // (fused dense path: no linked scales)
       if (seg - A.seg_begin < kSmallSegs) { seg_e[seg - A.seg_begin] = e; seg_lp[seg - A.seg_begin] = lp; }
     }
   }
@@ -939,21 +949,23 @@ __device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s, double
   return 0.0;
 }
 
-template <typename T>
+// FULL = false: only the constant-scale families Normal / Laplace / Student-t / Cauchy (BASELINE's configs): the
+// lean variant the host selects unless some segment has a generalised-normal, hierarchical or hyper prior
+template <typename T, bool FULL>
 __device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_data, bool calc_logp,
                                            const GradParts& G) {
   const int64_t chunk = blockIdx.x;
   const ChunkCtx cx = chunk_ctx(L, chunk);
   const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
   const bool parts = G.gpart != nullptr;
-  const bool linked = sp->scale_link > 0;
+  const bool linked = FULL && sp->scale_link > 0;
   double acc[2] = {0.0, 0.0};   // log-density partial; d/dscale of it (hierarchical scales)
   if ((sp->prior_kind != SGMCMC_PRIOR_NONE || parts) && sp->g != nullptr) {
     T* __restrict__ gp = (T*)sp->g + cx.seg_off;
     const T* __restrict__ thp = (const T*)sp->theta + cx.seg_off;
     const float* __restrict__ pp = parts ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
     PriorCoef<T> PC;
-    PC.init(L, sp, num_data);
+    PC.template init<FULL>(L, sp, num_data);
     for (int it = 0; it < items_of(L); ++it) {
       const int j = (it * kThreads + threadIdx.x) * 4;
       const int n = cx.n_valid - j < 4 ? cx.n_valid - j : 4;
@@ -962,7 +974,7 @@ __device__ __forceinline__ void prior_body(const sgmcmc_layout& L, double num_da
       const Item<T> th = load_guarded<T>(thp + j, n);
 #pragma unroll
       for (int l = 0; l < 4; ++l)
-        if (l < n) g.x[l] = PC.apply(g.x[l], th.x[l], calc_logp, acc[0], acc[1]);
+        if (l < n) g.x[l] = PC.template apply<FULL>(g.x[l], th.x[l], calc_logp, acc[0], acc[1]);
       store_guarded<T>(gp + j, g, n);
     }
   }
@@ -991,16 +1003,16 @@ __global__ __launch_bounds__(kThreads) void hyper_link_kernel(sgmcmc_layout L, d
   }
 }
 
-template <typename T>
+template <typename T, bool FULL>
 __global__ __launch_bounds__(kThreads) void prior_kernel(sgmcmc_layout L, double num_data,
                                                          int calc_logp, GradParts G) {
-  prior_body<T>(L, num_data, calc_logp != 0, G);
+  prior_body<T, FULL>(L, num_data, calc_logp != 0, G);
 }
 template <typename T>
 __global__ __launch_bounds__(kThreads) void prior_kernel_indirect(sgmcmc_layout L, double num_data,
                                                                   const sgmcmc_step_args* Ap,
                                                                   GradParts G) {
-  prior_body<T>(L, num_data, (Ap->flags & SGMCMC_CALC_METRICS) != 0, G);
+  prior_body<T, false>(L, num_data, (Ap->flags & SGMCMC_CALC_METRICS) != 0, G);
 }
 
 __global__ __launch_bounds__(kThreads) void finalize_prior_kernel(sgmcmc_layout L) {
@@ -1279,10 +1291,14 @@ int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
-  if (L->dtype == SGMCMC_F32)
-    SGMCMC_LAUNCH(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
-  else
-    SGMCMC_LAUNCH(prior_kernel<double>, grid, block, 0, s, *L, num_data, calc_log_prob, none);
+  const bool full = (flags & (SGMCMC_PRIOR_HAS_LINKS | SGMCMC_PRIOR_FULL)) != 0;
+  if (L->dtype == SGMCMC_F32) {
+    if (full) SGMCMC_LAUNCH((prior_kernel<float, true>), grid, block, 0, s, *L, num_data, calc_log_prob, none);
+    else SGMCMC_LAUNCH((prior_kernel<float, false>), grid, block, 0, s, *L, num_data, calc_log_prob, none);
+  } else {
+    if (full) SGMCMC_LAUNCH((prior_kernel<double, true>), grid, block, 0, s, *L, num_data, calc_log_prob, none);
+    else SGMCMC_LAUNCH((prior_kernel<double, false>), grid, block, 0, s, *L, num_data, calc_log_prob, none);
+  }
   if (flags & SGMCMC_PRIOR_HAS_LINKS) {
     if (L->dtype == SGMCMC_F32) SGMCMC_LAUNCH(hyper_link_kernel<float>, dim3(1), block, 0, s, *L, num_data);
     else SGMCMC_LAUNCH(hyper_link_kernel<double>, dim3(1), block, 0, s, *L, num_data);
@@ -1309,7 +1325,7 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
     SGMCMC_LAUNCH(prior_kernel_indirect<float>, grid, block, 0, s, *L, num_data, A_dev, G);
   else {
     const int calc = (int)((flags & SGMCMC_CALC_METRICS) != 0);
-    SGMCMC_LAUNCH(prior_kernel<float>, grid, block, 0, s, *L, num_data, calc, G);
+    SGMCMC_LAUNCH((prior_kernel<float, false>), grid, block, 0, s, *L, num_data, calc, G);
     if (calc) {  // no sampler launch follows to finish the log-prior: do it here
       SGMCMC_LAUNCH(finalize_prior_kernel, dim3((unsigned)L->n_seg), dim3(kThreads), 0, s, *L);
       SGMCMC_LAUNCH(total_prior_kernel, dim3(1), dim3(64), 0, s, *L);
@@ -1335,5 +1351,6 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "conv_hip.inc"
 #include "conv_down_hip.inc"
 #include "bn_hip.inc"
+#include "conv_fused_hip.inc"
 #include "pool_hip.inc"
 #include "augment_hip.inc"

@@ -376,7 +376,9 @@ class Engine:
         self.flush()
         _hip.check(self.lib.sgmcmc_prior_grad(ctypes.byref(self.layout), float(num_data),
                                               int(bool(calc_log_prob)),
-                                              _hip.PRIOR_HAS_LINKS if self.prior_links else 0, self.stream()),
+                                              (_hip.PRIOR_HAS_LINKS if self.prior_links else 0)
+                                              | (_hip.PRIOR_FULL if self.prior_max_kind > _hip.PRIOR_CAUCHY else 0),
+                                              self.stream()),
                    "sgmcmc_prior_grad")
         if calc_log_prob:
             self._touch()

@@ -20,6 +20,7 @@ from .. import bn as _bn
 from .. import conv as _conv
 from .. import pool as _pool
 from .. import prior
+from .. import resblock as _resblock
 from .base import ClassificationModel, RegressionModel
 
 __all__ = ("Linear", "Conv2d", "LinearPrior", "Conv2dPrior", "DenseNet", "ClassificationDenseNet",
@@ -290,6 +291,10 @@ class BasicBlock(nn.Module):
         m = self.main
         if isinstance(m[1], _BatchNorm2d):        # conv, BN+ReLU, conv, BN + shortcut + ReLU
             sc = self.shortcut
+            if (isinstance(sc, nn.Identity) and isinstance(m[0], Conv2d) and isinstance(m[3], Conv2d)
+                    and isinstance(m[4], _BatchNorm2d) and _bn.ENABLED
+                    and _resblock.supported(x, m[0], m[1], m[3], m[4])):
+                return _resblock.residual_block(x, m[0], m[1], m[3], m[4])      # the whole block: 3 launches each way
             if isinstance(sc, nn.Sequential) and self._down_fused(x):
                 # down-sampling block: the strided 3x3 and the 1x1 shortcut read the same x -- one kernel
                 want = m[1].training and m[1].track_running_stats and _bn.ENABLED

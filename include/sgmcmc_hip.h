@@ -75,7 +75,9 @@ enum {
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
        SGMCMC_PRIOR_STUDENT_T = 3, SGMCMC_PRIOR_CAUCHY = 4, SGMCMC_PRIOR_GENNORM = 5,
        SGMCMC_PRIOR_GAMMA_SOFTPLUS = 6, SGMCMC_PRIOR_UNIFORM_CDF = 7, SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS = 8 };
-enum { SGMCMC_PRIOR_HAS_LINKS = 1 }; /* flags of sgmcmc_prior_grad */
+/* flags of sgmcmc_prior_grad: some segment is linked to a hyper segment / some segment's kind is beyond CAUCHY
+ * (without either the lean kernel for the four constant-scale families is launched) */
+enum { SGMCMC_PRIOR_HAS_LINKS = 1, SGMCMC_PRIOR_FULL = 2 };
 
 /* One parameter tensor.  Device-resident array, written by the host. */
 typedef struct {
@@ -445,6 +447,48 @@ int sgmcmc_pool_linear_fwd(const float* h, const float* weight, const float* bia
 int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const float* weight, float* dh,
                            float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
                            void* stream);
+
+/* ---- a residual block of the ResNet trunk as three launches each way (csrc/conv_fused_hip.inc) -------------
+ *     y1 = conv1(x)   h = relu(bn1(y1))   y2 = conv2(h)   out = relu(bn2(y2) + x)      (google_resnet.py:34-43,77-90)
+ * BatchNorm is carried as per-channel coefficient arrays:  coef [4][C] = scale (gamma*invstd), shift
+ * (beta - mean*scale), mean, invstd;  bcoef [3][C] = k (gamma*invstd), mdb (sum dz / M), mdg (sum dz*xhat / M).
+ * `ticket`: one zero-initialised unsigned per call site (left at zero again by every launch); `stats` / `esums`:
+ * [C][sgmcmc_conv3x3_stat_slices(...)][2] doubles of per-band partials.
+ *
+ * sgmcmc_block_conv_fwd: y = conv3x3(in) with in = x (in_coef == NULL) or relu(in_coef.scale*x + in_coef.shift),
+ *   plus the batch statistics of y finished INSIDE the launch: coef <- BatchNorm(gamma, beta) coefficients of y,
+ *   running_mean / running_var updated as nn.BatchNorm2d does (both or neither).
+ * sgmcmc_block_apply: out = relu(coef.scale*y + coef.shift + residual).
+ * sgmcmc_block_bwd_sums: bcoef / dgamma / dbeta of the block's LAST BatchNorm from dout, out (ReLU mask) and y. */
+int sgmcmc_block_conv_fwd(const float* x, const float* w, const float* in_coef, float* y, double* stats, float* coef,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          double momentum, double eps, unsigned int* ticket, int n_img, int channels, int hw,
+                          void* stream);
+int sgmcmc_block_apply(const float* y, const float* residual, const float* coef, float* out, int n, int channels,
+                       int plane, void* stream);
+int64_t sgmcmc_block_sums_doubles(int n, int channels, int plane);
+int sgmcmc_block_bwd_sums(const float* dout, const float* out, const float* y, const float* coef, const float* gamma,
+                          double* scratch, float* bcoef, float* dgamma, float* dbeta, unsigned int* ticket, int n,
+                          int channels, int plane, void* stream);
+/* Both gradients of one of the block's convolutions in one launch, with the BatchNorm backward that precedes it
+ * folded into the operand staging and the one that follows folded into the data-gradient epilogue:
+ *   dy = k*(dz - mdb - xhat*mdg), xhat = (y - mean)*invstd, from dz / y / coef / bcoef      (both modes)
+ *   mode 2 (second convolution): dz = dz_in*[mask_out > 0]; weight-gradient input h = relu(xcoef.scale*x + xcoef.shift);
+ *     epilogue: dx <- dgrad*[relu(ecoef.scale*ye + ecoef.shift) > 0] (= dz of the FIRST BatchNorm) and that
+ *     BatchNorm's ebcoef / edgamma / edbeta, finished inside the launch
+ *   mode 3 (first convolution): dz given as is; weight-gradient input x; epilogue: dx <- dgrad + e_dout*[e_out > 0]
+ * dw is left as *n_slabs partial slabs in `scratch` (sgmcmc_conv3x3_wrw_scratch_floats) for sgmcmc_wrw_reduce_many. */
+typedef struct {
+  const float *dz, *mask_out, *y, *coef, *bcoef, *xcoef;
+  const float *ye, *ecoef, *egamma;
+  double* esums;
+  float *ebcoef, *edgamma, *edbeta;
+  const float *e_dout, *e_out;
+  unsigned int* ticket;
+} sgmcmc_block_bwd_args;
+int sgmcmc_block_conv_bwd(int mode, const float* x, const float* w, float* dx, float* scratch,
+                          const sgmcmc_block_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
+                          void* stream);
 
 /* Minibatch gather from an HBM-resident image set with random crop (zero padding `pad`) and horizontal flip
  * applied on the way -- the `cifar10_augmented` pipeline (data/CIFAR/cifar.py:136-172: RandomCrop(32,

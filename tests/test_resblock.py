@@ -1,0 +1,126 @@
+"""The fused residual block (csrc/conv_fused_hip.inc, bnn_priors_amd/resblock.py) against a float64 PyTorch
+statement of the same block -- conv3x3 -> BatchNorm(train) -> ReLU -> conv3x3 -> BatchNorm(train) -> (+x) -> ReLU
+(reference: bnn_priors/models/google_resnet.py:34-43, 77-90) -- forward value, running statistics and every
+gradient, at the three trunk shapes and batch sizes 128 / 5 / 1; plus run-to-run bit reproducibility (the
+cross-workgroup reductions are ordered) and agreement with this repo's layer-by-layer path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bnn_priors_amd import conv
+
+pytestmark = pytest.mark.gpu
+SHAPES = sorted(conv.SHAPES)
+
+
+def _block(c, seed=0):
+    from bnn_priors_amd.models import nets
+    from bnn_priors_amd import prior
+    torch.manual_seed(seed)
+    kw = dict(prior_w=prior.Normal, loc_w=0., std_w=2 ** .5, prior_b=None, scaling_fn=None,
+              weight_prior_params={}, bias_prior_params={})
+    blk = nets.BasicBlock(c, c, 1, kw, nets._BatchNorm2d).cuda()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nets._BatchNorm2d):
+                m.weight.copy_(torch.rand(c) + 0.5)
+                m.bias.copy_(torch.randn(c) * 0.3)
+                m.running_mean.copy_(torch.randn(c) * 0.1)
+                m.running_var.copy_(torch.rand(c) + 0.5)
+            if isinstance(m, nets.Conv2d):
+                m.weight_prior.p.mul_((2.0 / (9 * c)) ** .5 / m.weight_prior.p.std())
+    return blk
+
+
+def _reference(blk, x, dout):
+    "float64 autograd through plain PyTorch ops"
+    m = blk.main
+    p = dict(w1=m[0].weight_prior.p, g1=m[1].weight, b1=m[1].bias, w2=m[3].weight_prior.p, g2=m[4].weight, b2=m[4].bias)
+    q = {k: v.detach().double().requires_grad_() for k, v in p.items()}
+    xd = x.detach().double().requires_grad_()
+    rm = [m[1].running_mean.double().clone(), m[4].running_mean.double().clone()]
+    rv = [m[1].running_var.double().clone(), m[4].running_var.double().clone()]
+    y1 = F.conv2d(xd, q["w1"], None, 1, 1)
+    h = F.relu(F.batch_norm(y1, rm[0], rv[0], q["g1"], q["b1"], True, m[1].momentum, m[1].eps))
+    y2 = F.conv2d(h, q["w2"], None, 1, 1)
+    out = F.relu(F.batch_norm(y2, rm[1], rv[1], q["g2"], q["b2"], True, m[4].momentum, m[4].eps) + xd)
+    out.backward(dout.double())
+    return out.detach(), xd.grad, {k: v.grad for k, v in q.items()}, rm, rv
+
+
+def _run(blk, x, dout):
+    for p in blk.parameters():
+        p.grad = None
+    xs = x.detach().clone().requires_grad_()
+    out = blk(xs)
+    out.backward(dout)
+    m = blk.main
+    grads = dict(w1=m[0].weight_prior.p.grad, g1=m[1].weight.grad, b1=m[1].bias.grad, w2=m[3].weight_prior.p.grad,
+                 g2=m[4].weight.grad, b2=m[4].bias.grad)
+    return out.detach(), xs.grad, {k: v.clone() for k, v in grads.items()}
+
+
+@pytest.mark.parametrize("c,hw", SHAPES)
+@pytest.mark.parametrize("n", [128, 5, 1])
+def test_fused_block_matches_float64_reference(c, hw, n):
+    from bnn_priors_amd import resblock
+    blk = _block(c)
+    blk.train()
+    g = torch.Generator().manual_seed(100 * c + n)
+    x = torch.relu(torch.randn(n, c, hw, hw, generator=g)).cuda()           # a block's input is post-ReLU
+    dout = torch.randn(n, c, hw, hw, generator=g).cuda()
+    assert resblock.supported(x, blk.main[0], blk.main[1], blk.main[3], blk.main[4])
+    ref_out, ref_dx, ref_g, rm, rv = _reference(blk, x, dout)                # (before the running stats move)
+    out, dx, grads = _run(blk, x, dout)
+    m = blk.main
+    scale = lambda t: max(1.0, t.abs().max().item())
+    torch.testing.assert_close(out.double(), ref_out, rtol=1e-4, atol=1e-4 * scale(ref_out))
+    torch.testing.assert_close(m[1].running_mean.double(), rm[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m[1].running_var.double(), rv[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m[4].running_mean.double(), rm[1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m[4].running_var.double(), rv[1], rtol=1e-5, atol=1e-6)
+    # gradients: fp32 accumulation over up to N*HW*HW terms; ReLU masks at |h| ~ rounding may flip single elements
+    torch.testing.assert_close(dx.double(), ref_dx, rtol=2e-3, atol=2e-4 * scale(ref_dx))
+    for k in ref_g:
+        torch.testing.assert_close(grads[k].double(), ref_g[k], rtol=2e-3, atol=3e-4 * scale(ref_g[k])), k
+
+
+@pytest.mark.parametrize("c,hw", SHAPES)
+def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw):
+    from bnn_priors_amd import resblock
+    g = torch.Generator().manual_seed(c)
+    x = torch.relu(torch.randn(64, c, hw, hw, generator=g)).cuda()
+    dout = torch.randn(64, c, hw, hw, generator=g).cuda()
+    runs = []
+    for _ in range(3):
+        blk = _block(c, seed=5)
+        blk.train()
+        runs.append(_run(blk, x, dout) + (blk.main[1].running_var.clone(),))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[3], runs[0][3])
+        for k in r[2]:
+            assert torch.equal(r[2][k], runs[0][2][k]), k
+    old = resblock.ENABLED
+    resblock.ENABLED = False
+    try:
+        blk = _block(c, seed=5)
+        blk.train()
+        layered = _run(blk, x, dout)
+    finally:
+        resblock.ENABLED = old
+    torch.testing.assert_close(runs[0][0], layered[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(runs[0][1], layered[1], rtol=2e-3, atol=2e-4 * max(1.0, layered[1].abs().max().item()))
+    for k in layered[2]:
+        torch.testing.assert_close(runs[0][2][k], layered[2][k], rtol=2e-3,
+                                   atol=3e-4 * max(1.0, layered[2][k].abs().max().item()))
+
+
+def test_eval_mode_and_off_table_shapes_take_the_layered_path():
+    from bnn_priors_amd import resblock
+    blk = _block(16)
+    x = torch.randn(4, 16, 32, 32).cuda()
+    blk.eval()
+    assert not resblock.supported(x, blk.main[0], blk.main[1], blk.main[3], blk.main[4])
+    blk.train()
+    assert not resblock.supported(torch.randn(4, 16, 16, 16).cuda(), blk.main[0], blk.main[1], blk.main[3], blk.main[4])
+    assert resblock.supported(x, blk.main[0], blk.main[1], blk.main[3], blk.main[4])
