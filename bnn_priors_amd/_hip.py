@@ -76,11 +76,11 @@ class ReduceJob(ctypes.Structure):
                 ("numel", ctypes.c_int32)]
 
 
-class BlockBwdArgs(ctypes.Structure):
-    "sgmcmc_block_bwd_args"
-    _fields_ = [(name, ctypes.c_void_p) for name in (
-        "dz", "mask_out", "y", "coef", "bcoef", "xcoef", "ye", "ecoef", "egamma", "esums", "ebcoef", "edgamma",
-        "edbeta", "e_dout", "e_out", "ticket")]
+class ConvBnBwdArgs(ctypes.Structure):
+    "sgmcmc_conv_bn_bwd_args"
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("dout", "mask_out", "y", "mean", "invstd", "gamma", "sums")]
+                + [("n_sums", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                + [(n, ctypes.c_void_p) for n in ("dgamma", "dbeta", "e_dout", "e_out")])
 
 
 class GradParts(ctypes.Structure):
@@ -189,12 +189,9 @@ EXPORTS = {
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
-    "sgmcmc_block_conv_fwd": (ctypes.c_int, [ctypes.c_void_p] * 10 + [ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
-                              + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
-    "sgmcmc_block_apply": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
-    "sgmcmc_block_sums_doubles": (ctypes.c_int64, [ctypes.c_int] * 3),
-    "sgmcmc_block_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 10 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
-    "sgmcmc_block_conv_bwd": (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.POINTER(BlockBwdArgs)]
+    "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3
+                           + [ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
                               + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_first_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),

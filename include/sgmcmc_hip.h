@@ -448,46 +448,31 @@ int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const floa
                            float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
                            void* stream);
 
-/* ---- a residual block of the ResNet trunk as three launches each way (csrc/conv_fused_hip.inc) -------------
- *     y1 = conv1(x)   h = relu(bn1(y1))   y2 = conv2(h)   out = relu(bn2(y2) + x)      (google_resnet.py:34-43,77-90)
- * BatchNorm is carried as per-channel coefficient arrays:  coef [4][C] = scale (gamma*invstd), shift
- * (beta - mean*scale), mean, invstd;  bcoef [3][C] = k (gamma*invstd), mdb (sum dz / M), mdg (sum dz*xhat / M).
- * `ticket`: one zero-initialised unsigned per call site (left at zero again by every launch); `stats` / `esums`:
- * [C][sgmcmc_conv3x3_stat_slices(...)][2] doubles of per-band partials.
+/* ---- BatchNorm backward folded into the convolution's gradient launch (csrc/conv_fused_hip.inc) ----------
+ * For a "conv3x3 -> BatchNorm(train) -> [+ shortcut] -> ReLU" pair of the ResNet trunk (google_resnet.py:34-43,
+ * 77-90), given dout = the gradient w.r.t. the pair's (post-ReLU) output `out`, y = the convolution's output:
  *
- * sgmcmc_block_conv_fwd: y = conv3x3(in) with in = x (in_coef == NULL) or relu(in_coef.scale*x + in_coef.shift),
- *   plus the batch statistics of y finished INSIDE the launch: coef <- BatchNorm(gamma, beta) coefficients of y,
- *   running_mean / running_var updated as nn.BatchNorm2d does (both or neither).
- * sgmcmc_block_apply: out = relu(coef.scale*y + coef.shift + residual).
- * sgmcmc_block_bwd_sums: bcoef / dgamma / dbeta of the block's LAST BatchNorm from dout, out (ReLU mask) and y. */
-int sgmcmc_block_conv_fwd(const float* x, const float* w, const float* in_coef, float* y, double* stats, float* coef,
-                          const float* gamma, const float* beta, float* running_mean, float* running_var,
-                          double momentum, double eps, unsigned int* ticket, int n_img, int channels, int hw,
-                          void* stream);
-int sgmcmc_block_apply(const float* y, const float* residual, const float* coef, float* out, int n, int channels,
-                       int plane, void* stream);
-int64_t sgmcmc_block_sums_doubles(int n, int channels, int plane);
-int sgmcmc_block_bwd_sums(const float* dout, const float* out, const float* y, const float* coef, const float* gamma,
-                          double* scratch, float* bcoef, float* dgamma, float* dbeta, unsigned int* ticket, int n,
-                          int channels, int plane, void* stream);
-/* Both gradients of one of the block's convolutions in one launch, with the BatchNorm backward that precedes it
- * folded into the operand staging and the one that follows folded into the data-gradient epilogue:
- *   dy = k*(dz - mdb - xhat*mdg), xhat = (y - mean)*invstd, from dz / y / coef / bcoef      (both modes)
- *   mode 2 (second convolution): dz = dz_in*[mask_out > 0]; weight-gradient input h = relu(xcoef.scale*x + xcoef.shift);
- *     epilogue: dx <- dgrad*[relu(ecoef.scale*ye + ecoef.shift) > 0] (= dz of the FIRST BatchNorm) and that
- *     BatchNorm's ebcoef / edgamma / edbeta, finished inside the launch
- *   mode 3 (first convolution): dz given as is; weight-gradient input x; epilogue: dx <- dgrad + e_dout*[e_out > 0]
- * dw is left as *n_slabs partial slabs in `scratch` (sgmcmc_conv3x3_wrw_scratch_floats) for sgmcmc_wrw_reduce_many. */
+ *   sgmcmc_bn_bwd_sums: per-slice partial sums of dz = dout*[out>0] and dz*xhat, [channels][*n_sums][2] doubles
+ *     (sgmcmc_bn_scratch_doubles(...) doubles) -- the first launch of sgmcmc_bn_train_bwd on its own;
+ *   sgmcmc_conv3x3_bn_bwd: BOTH gradients of the convolution with
+ *       dy = gamma*invstd * (dz - sum dz / M - xhat * sum(dz*xhat) / M),  xhat = (y - mean)*invstd
+ *     formed while the operands are staged (what sgmcmc_bn_train_bwd's second launch would have written), plus
+ *     dgamma = sum dz*xhat, dbeta = sum dz.  With e_dout / e_out given, dx += e_dout*[e_out > 0]: the gradient
+ *     that reaches the convolution's INPUT through a shortcut whose ReLU mask is e_out (replaces an add launch).
+ *     dw is left as *n_slabs partial slabs in `scratch` (sgmcmc_conv3x3_wrw_scratch_floats) for
+ *     sgmcmc_wrw_reduce_many, as sgmcmc_conv3x3_bwd does with deferred_slabs. */
 typedef struct {
-  const float *dz, *mask_out, *y, *coef, *bcoef, *xcoef;
-  const float *ye, *ecoef, *egamma;
-  double* esums;
-  float *ebcoef, *edgamma, *edbeta;
+  const float *dout, *mask_out, *y, *mean, *invstd, *gamma;
+  const double* sums;
+  int32_t n_sums, reserved;
+  float *dgamma, *dbeta;
   const float *e_dout, *e_out;
-  unsigned int* ticket;
-} sgmcmc_block_bwd_args;
-int sgmcmc_block_conv_bwd(int mode, const float* x, const float* w, float* dx, float* scratch,
-                          const sgmcmc_block_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
+} sgmcmc_conv_bn_bwd_args;
+int sgmcmc_bn_bwd_sums(const float* dout, const float* out, const float* y, const float* save_mean,
+                       const float* save_invstd, double* sums, int* n_sums, int n, int channels, int plane,
+                       void* stream);
+int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scratch,
+                          const sgmcmc_conv_bn_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
                           void* stream);
 
 /* Minibatch gather from an HBM-resident image set with random crop (zero padding `pad`) and horizontal flip

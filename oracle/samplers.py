@@ -299,14 +299,18 @@ class RefVerletSGLD(_RefBase):
 
 
 class RefHMC(RefVerletSGLD):
-    """Leapfrog HMC (a = 1, T = 1, no noise draw); mcmc/hmc.py:25-79."""
+    """Leapfrog HMC (a = 1, T = 1, no noise draw); mcmc/hmc.py:25-79.  ``temperature`` != 1 is the build's
+    extension for BASELINE configs[4] (the reference asserts T == 1): same leapfrog map, momentum refresh
+    N(0, T) and acceptance exp(-dH/T) as the base class already implements them."""
 
-    def __init__(self, params, lr, num_data, raise_on_no_grad=True, raise_on_nan=True, noise=None):
-        super().__init__(params, lr, num_data, 1., 1., raise_on_no_grad=raise_on_no_grad,
+    def __init__(self, params, lr, num_data, raise_on_no_grad=True, raise_on_nan=True, noise=None,
+                 temperature=1.):
+        self._tempered = temperature != 1.
+        super().__init__(params, lr, num_data, 1., temperature, raise_on_no_grad=raise_on_no_grad,
                          raise_on_nan=raise_on_nan, noise=noise)
 
     def _check_group(self, g):
-        assert g['momentum'] == 1. and g['temperature'] == 1.  # mcmc/hmc.py:39
+        assert g['momentum'] == 1. and (self._tempered or g['temperature'] == 1.)  # mcmc/hmc.py:39
 
     def _point_energy(self, group, p, state):
         return .5 * _dot(state['momentum_buffer'], state['momentum_buffer'])  # mcmc/hmc.py:32-33

@@ -38,6 +38,13 @@ SCENARIOS = {
     "verlet_dense": dict(kind="verlet", model="dense", a=0.9, T=1.0, lr=0.01, N=32),
     "hmc_dense": dict(kind="hmc", model="dense", a=1.0, T=1.0, lr=0.005, N=32),
 }
+# ---- BASELINE configs[4]: HMC trajectories of L = 50 leapfrog steps at T in {1, 0.1, 0.01} (T != 1 extends the
+# reference, whose HMC asserts T == 1: no reference goldens exist for these; HIP is compared with the oracle)
+TEMPERED = {
+    f"hmc_dense_L50_T{T:g}": dict(kind="hmc", model="dense", a=1.0, T=T, lr=0.002 * T, N=32, n_steps=100,
+                                  mh_every=50, lr_decay=1.0, tempered=True)
+    for T in (1.0, 0.1, 0.01)
+}
 DTYPES = ("float32", "float64")
 N_STEPS, MH_EVERY, LR_DECAY, SEED = 24, 4, 0.97, 20240607
 
@@ -77,6 +84,9 @@ def drive(opt, model, closure, cfg, hooks, record_every=4):
     mapping of parameter ``p`` and ``hooks.flat(tensors)`` a float64 numpy copy.
     """
     kind = cfg["kind"]
+    # the schedule: module defaults unless the scenario overrides them (TEMPERED)
+    N_STEPS, MH_EVERY, LR_DECAY = (cfg.get("n_steps", globals()["N_STEPS"]), cfg.get("mh_every", globals()["MH_EVERY"]),
+                                   cfg.get("lr_decay", globals()["LR_DECAY"]))
     params = list(model.parameters())
     rec = dict(theta=[], mom=[], rec_steps=[], delta_energy=[], prev_delta=[], est_temp=[],
                est_cfg=[], mh_delta_energy=[], mh_log_acc=[], mh_rejected=[], mh_step=[],
@@ -180,6 +190,8 @@ def preset(model, opt, cfg, dtype, state_of):
 def build_optimizer(classes, params, cfg, **extra):
     "classes = dict(sgld=..., verlet=..., hmc=...)"
     if cfg["kind"] == "hmc":
+        if cfg.get("tempered"):
+            extra = dict(extra, temperature=cfg["T"])
         return classes["hmc"](params, lr=cfg["lr"], num_data=cfg["N"], **extra)
     return classes[cfg["kind"]](params, lr=cfg["lr"], num_data=cfg["N"], momentum=cfg["a"],
                                 temperature=cfg["T"], **extra)

@@ -125,8 +125,13 @@ def test_abi_rejects_shapes_outside_the_table():
 
 @pytest.mark.gpu
 def test_resnet_layers_take_the_kernel_path(monkeypatch):
-    "the googleresnet trunk routes its 16 stride-1 3x3 convolutions through conv3x3; switch = env/flag"
-    from bnn_priors_amd import models
+    """the googleresnet trunk routes its 16 stride-1 3x3 convolutions through the hand-written kernels: the seven
+    identity-shortcut blocks as fused blocks (resblock.py, 2 convolutions each), the conv2 of the two down-sampling
+    blocks through conv3x3, their strided pair through conv_down; switches = env / module flags"""
+    from bnn_priors_amd import models, resblock
+    blocks = []
+    real_block = resblock.residual_block
+    monkeypatch.setattr(resblock, "residual_block", lambda x, *a: (blocks.append(tuple(x.shape[1:3])), real_block(x, *a))[1])
     calls = []
     real = conv.conv3x3
     monkeypatch.setattr(conv, "conv3x3",
@@ -142,16 +147,24 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
     monkeypatch.setattr(conv, "conv_down", lambda x, wm, ws, want_stats=False:
                         (downs.append(tuple(x.shape[1:3])), real_down(x, wm, ws, want_stats))[1])
     out = net.net(x.cuda())
-    assert sorted(calls) == [(16, 32)] * 6 + [(32, 16)] * 5 + [(64, 8)] * 5
+    assert sorted(blocks) == [(16, 32)] * 3 + [(32, 16)] * 2 + [(64, 8)] * 2
+    assert sorted(calls) == [(32, 16), (64, 8)]
     assert sorted(downs) == [(16, 32), (32, 16)]
+    monkeypatch.setattr(resblock, "ENABLED", False)       # layer by layer: every stride-1 3x3 goes through conv3x3
+    calls.clear(); blocks.clear(); downs.clear()
+    layered = net.net(x.cuda())
+    assert not blocks and sorted(calls) == [(16, 32)] * 6 + [(32, 16)] * 5 + [(64, 8)] * 5
+    torch.testing.assert_close(layered, out, rtol=1e-3, atol=1e-3)
+    monkeypatch.setattr(resblock, "ENABLED", True)
     monkeypatch.setattr(conv, "ENABLED", False)
     calls.clear()
     downs.clear()
+    blocks.clear()
     net.eval()
     ref = net.net(x.cuda())
-    assert not calls and not downs
+    assert not calls and not downs and not blocks
     monkeypatch.setattr(conv, "ENABLED", True)
-    torch.testing.assert_close(net.net(x.cuda()), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(net.net(x.cuda()), ref, rtol=5e-4, atol=1e-3)      # own kernels vs MIOpen, 20 layers deep
     assert out.shape == (4, 10)
 
 
