@@ -27,6 +27,12 @@ from . import _hip
 from . import conv as _conv
 
 ENABLED = os.environ.get("SGMCMC_BLOCK", "1") != "0"
+# (channels, side) for which the BatchNorm backward is formed inside the convolution-gradient launch.  Measured on
+# MI355X (profiles/): 32 @ 16x16 and 64 @ 8x8 gain 1-5 us per pair over bwd_dx + conv3x3_bwd; at 16 @ 32x32 the three
+# 8 MB operand tensors staged by BOTH the data- and the weight-gradient workgroups cost 4 us more than the extra
+# launch saves, so that shape keeps the two-launch BatchNorm backward (and only fuses the shortcut's add).
+FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") == "" else \
+    {tuple(int(v) for v in item.split("x")) for item in os.environ["SGMCMC_BLOCK_FUSED"].split(",") if item}
 
 
 def supported(x, conv1, bn1, conv2, bn2):
@@ -72,8 +78,45 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
     return y, out, saved
 
 
+def _reduce_or_defer(lib, w, part, n_slabs, s):
+    dw = torch.empty_like(w)
+    if _conv._may_defer(w):      # summed with the pass's other slabs by ONE launch at its end
+        torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
+        _conv._pending.append((part, dw, n_slabs))
+        return dw.view(dw.shape)
+    job = (_hip.ReduceJob * 1)()
+    job[0].part, job[0].out, job[0].n_slabs, job[0].numel = part.data_ptr(), dw.data_ptr(), n_slabs, dw.numel()
+    err = lib.sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, s)
+    if err:
+        _hip.check(err, "sgmcmc_wrw_reduce_many")
+    return dw
+
+
+def _conv_bn_bwd_two_launch(lib, x, w, y, out, dout, saved, g, dgb, want_dz, s):
+    """the same gradients with the BatchNorm backward as its own two launches (sums, dx) before conv3x3_bwd;
+    ``want_dz``: also return dz = dout * [out > 0] (what the shortcut carries)"""
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=x.device)
+    dy = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    err = lib.sgmcmc_bn_train_bwd(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
+                                  saved[1].data_ptr(), 1, n, c, hw * hw, dy.data_ptr(), _p(dz), dgb[0].data_ptr(),
+                                  dgb[1].data_ptr(), scratch.data_ptr(), s)
+    if err:
+        _hip.check(err, "sgmcmc_bn_train_bwd")
+    part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    slabs = ctypes.c_int(0)
+    err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), n, c, hw,
+                                 ctypes.byref(slabs), s)
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_bwd")
+    return dx, _reduce_or_defer(lib, w, part, slabs.value, s), dz
+
+
 def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
-    "gradients of (x, w) through out = relu(bn(conv3x3(x, w)) [+ r]) given dout; dgb [2][C] <- dgamma, dbeta"
+    """gradients of (x, w) through out = relu(bn(conv3x3(x, w)) [+ r]) given dout, BatchNorm backward inside the
+    convolution-gradient launch; dgb [2][C] <- dgamma, dbeta; e_dout / e_out: dx += e_dout * [e_out > 0]"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=x.device)
     n_sums = ctypes.c_int(0)
@@ -92,17 +135,7 @@ def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
                                     hw, ctypes.byref(slabs), s)
     if err:
         _hip.check(err, "sgmcmc_conv3x3_bn_bwd")
-    dw = torch.empty_like(w)
-    if _conv._may_defer(w):      # summed with the pass's other slabs by ONE launch at its end
-        torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
-        _conv._pending.append((part, dw, slabs.value))
-        return dx, dw.view(dw.shape)
-    job = (_hip.ReduceJob * 1)()
-    job[0].part, job[0].out, job[0].n_slabs, job[0].numel = part.data_ptr(), dw.data_ptr(), slabs.value, dw.numel()
-    err = lib.sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, s)
-    if err:
-        _hip.check(err, "sgmcmc_wrw_reduce_many")
-    return dx, dw
+    return dx, _reduce_or_defer(lib, w, part, slabs.value, s)
 
 
 class _Block(torch.autograd.Function):
@@ -125,9 +158,14 @@ class _Block(torch.autograd.Function):
         dout = dout.contiguous()
         s = _stream()
         dgb = torch.empty((2, 2, x.shape[1]), dtype=torch.float32, device=x.device)
-        dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
-        # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue
-        dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
+        if (x.shape[1], x.shape[2]) in FUSED_BN_BWD:
+            dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
+            # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue
+            dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
+        else:
+            dh, dw2, dz2 = _conv_bn_bwd_two_launch(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], True, s)
+            dx, dw1, _ = _conv_bn_bwd_two_launch(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], False, s)
+            dx.add_(dz2)
         return (dx, dw1, dgb[0, 0], dgb[0, 1], dw2, dgb[1, 0], dgb[1, 1]) + (None,) * 8
 
 

@@ -464,7 +464,9 @@ def test_tempered_hmc_trajectories_match_the_oracle(name):
             S.preset(model, opt, cfg, torch.float32, lambda p: opt.state[p])
             got = S.drive(opt, model, closure, cfg, PlainHooks(opt), record_every=10)
         gold = {f"{name}/{k}": v for k, v in want.items()}
-        compare(got, gold, name, rtol=5e-4, atol=5e-5, u_eps=2.0 ** -23)
+        # dE is a difference of O(N*U) terms: at T = 0.01 the step is tiny and |dE| ~ 1e-5, so log_acc = -dE/T
+        # carries the fp32 noise of the potentials divided by T on top of the general tolerance
+        compare(got, gold, name, rtol=5e-4, atol=5e-5 + 2e-5 / cfg["T"], u_eps=2.0 ** -23)
         assert len(got["mh_step"]) == 2 and list(got["mh_step"]) == [50, 100]
         # the momentum refresh draws N(0, T): kinetic temperature right after it is T within sampling error (d = 10..160)
         t_est = np.asarray(got["est_temp"])[1]          # the initial_step's estimate, per tensor

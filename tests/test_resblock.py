@@ -60,10 +60,13 @@ def _run(blk, x, dout):
     return out.detach(), xs.grad, {k: v.clone() for k, v in grads.items()}
 
 
+@pytest.mark.parametrize("fused_bwd", [True, False])
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
-def test_fused_block_matches_float64_reference(c, hw, n):
+def test_fused_block_matches_float64_reference(c, hw, n, fused_bwd, monkeypatch):
     from bnn_priors_amd import resblock
+    # both backward routes at every shape: BatchNorm backward inside the convolution-gradient launch / as two launches
+    monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES) if fused_bwd else set())
     blk = _block(c)
     blk.train()
     g = torch.Generator().manual_seed(100 * c + n)
@@ -86,8 +89,9 @@ def test_fused_block_matches_float64_reference(c, hw, n):
 
 
 @pytest.mark.parametrize("c,hw", SHAPES)
-def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw):
+def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, monkeypatch):
     from bnn_priors_amd import resblock
+    monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES))
     g = torch.Generator().manual_seed(c)
     x = torch.relu(torch.randn(64, c, hw, hw, generator=g)).cuda()
     dout = torch.randn(64, c, hw, hw, generator=g).cuda()
