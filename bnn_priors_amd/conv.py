@@ -368,3 +368,60 @@ class _ConvFirst(torch.autograd.Function):
 def conv_first(x, w):
     "conv2d(x, w, padding=1) for x [N, 1, 28, 28] (no gradient), w [50, 1, 3, 3]"
     return _ConvFirst.apply(x, w)
+
+
+# ------------------------------------------------------------------ the convolutional classifier's second layer
+def conv50_supported(x, w, bias, stride, padding, dilation, groups):
+    "50 -> 50 channels, 3x3 / stride 1 / pad 1 on 14x14 maps (csrc/conv50_hip.inc); the bias joins the fused tail"
+    return (ENABLED and bias is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and tuple(x.shape[1:]) == (50, 14, 14) and x.shape[0] > 0 and tuple(w.shape) == (50, 50, 3, 3)
+            and w.dtype == torch.float32 and groups == 1 and _pair(stride) == (1, 1) and _pair(padding) == (1, 1)
+            and _pair(dilation) == (1, 1))
+
+
+class _Conv50(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        _note_use(w)
+        x, w = x.contiguous(), w.contiguous()
+        y = torch.empty_like(x)
+        err = _hip.lib().sgmcmc_conv50(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], 0, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv50")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = _hip.lib()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n = x.shape[0]
+        if not ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            err = lib.sgmcmc_conv50(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, 1, _stream())
+            if err:
+                _hip.check(err, "sgmcmc_conv50")
+            return dx, None
+        scratch = torch.empty(lib.sgmcmc_conv50_scratch_floats(n), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        defer = _may_defer(w)
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv50_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0 if dx is None else dx.data_ptr(),
+                                    dw.data_ptr(), scratch.data_ptr(), n, ctypes.byref(slabs) if defer else None,
+                                    _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv50_bwd")
+        if defer:
+            _pending.append((scratch, dw, slabs.value))
+            return dx, dw.view(dw.shape)
+        return dx, dw
+
+
+def conv50(x, w):
+    "conv2d(x, w, padding=1) for x [N, 50, 14, 14], w [50, 50, 3, 3]"
+    return _Conv50.apply(x, w)

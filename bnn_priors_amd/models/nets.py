@@ -47,7 +47,10 @@ class Linear(_PriorBacked):
         self.out_features, self.in_features = weight_prior.p.shape
 
     def forward(self, x):
-        return nn.functional.linear(x, self.weight, self.bias)
+        w, b = self.weight, self.bias
+        if _pool.linear_supported(x, w, b):        # a head with a few outputs: one launch each way (pool.linear)
+            return _pool.linear(x, w, b)
+        return nn.functional.linear(x, w, b)
 
 
 class Conv2d(_PriorBacked):
@@ -168,6 +171,8 @@ class _ConvPoolTrunk(nn.Sequential):
                 w = m.weight                                                    # bias joins the fused tail
                 if _conv.first_supported(x, w, None, *m.conv_args):
                     y = _conv.conv_first(x, w)
+                elif _conv.conv50_supported(x, w, None, *m.conv_args):
+                    y = _conv.conv50(x, w)
                 else:
                     y = nn.functional.conv2d(x, w, None, *m.conv_args)
                 b = m.bias

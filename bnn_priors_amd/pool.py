@@ -145,6 +145,58 @@ def pool_linear(h, weight, bias=None):
     return _PoolLinear.apply(h, weight, bias)
 
 
+# ------------------------------------------------------------------ narrow linear layer
+def linear_supported(x, weight, bias):
+    "x [N, J] float32 on the GPU, weight [K <= 16, J]: the convolutional classifier's head (csrc/pool_hip.inc, lin)"
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+            and weight.dim() == 2 and weight.shape[1] == x.shape[1] and weight.shape[0] <= 16
+            and weight.dtype == torch.float32
+            and (bias is None or (bias.dtype == torch.float32 and bias.shape == (weight.shape[0],))))
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _conv._note_use(weight)
+        x, weight = x.contiguous(), weight.contiguous()
+        y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+        err = _hip.lib().sgmcmc_linear_fwd(x.data_ptr(), weight.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                           y.data_ptr(), x.shape[0], x.shape[1], weight.shape[0], _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_linear_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        lib = _hip.lib()
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        slabs = None
+        if ctx.needs_input_grad[1]:
+            slabs = torch.empty((lib.sgmcmc_linear_row_groups(x.shape[0]),) + tuple(weight.shape), dtype=torch.float32,
+                                device=x.device)
+        db = (torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+              if ctx.has_bias and ctx.needs_input_grad[2] else None)
+        p = lambda t: 0 if t is None else t.data_ptr()
+        err = lib.sgmcmc_linear_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), p(dx), p(slabs), p(db),
+                                    x.shape[0], x.shape[1], weight.shape[0], _conv._stream())
+        if err:
+            _hip.check(err, "sgmcmc_linear_bwd")
+        dw = None
+        if slabs is not None:     # the row groups' slabs: summed with the pass's other slabs when nothing reads dw earlier
+            dw = _reduce_rows(slabs.view(slabs.shape[0], -1), torch.empty_like(weight), _conv._may_defer(weight))
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    "F.linear(x, weight, bias) for 2-D float32 x and at most 16 output features"
+    return _Linear.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------ softmax cross-entropy
 def xent_supported(logits, y):
     return (ENABLED and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2

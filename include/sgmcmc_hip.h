@@ -405,6 +405,16 @@ int64_t sgmcmc_conv_first_scratch_floats(int n_img);
 int sgmcmc_conv_first_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                           int* deferred_slabs, void* stream);
 
+/* The convolutional classifier's SECOND convolution (models/conv_nets.py:46-70): 50 -> 50 channels, 3x3 / stride 1 /
+ * pad 1 on 14x14 maps, without its bias (see sgmcmc_bias_relu_pool_*), on the fp32 matrix pipe (csrc/conv50_hip.inc).
+ *   sgmcmc_conv50: transpose_w = 0 forward, 1 data gradient (x = the gradient w.r.t. the forward output);
+ *   sgmcmc_conv50_bwd: data gradient (dx may be NULL: weight gradient only) and weight gradient in one launch;
+ *     scratch: sgmcmc_conv50_scratch_floats(n_img) floats of partial slabs; deferred_slabs as sgmcmc_conv3x3_bwd. */
+int sgmcmc_conv50(const float* x, const float* w, float* y, int n_img, int transpose_w, void* stream);
+int64_t sgmcmc_conv50_scratch_floats(int n_img);
+int sgmcmc_conv50_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* scratch, int n_img,
+                      int* deferred_slabs, void* stream);
+
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
  * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):
@@ -474,6 +484,17 @@ int sgmcmc_bn_bwd_sums(const float* dout, const float* out, const float* y, cons
 int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scratch,
                           const sgmcmc_conv_bn_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
                           void* stream);
+
+/* A narrow linear layer, y = x W^T + b with out_features <= 16 (the convolutional classifier's head,
+ * Flatten -> Linear(2450, 10), models/conv_nets.py:57-70): one launch each way, fixed-order reductions.
+ * Backward, one launch: dx (may be NULL), dbias (may be NULL) and the weight gradient as
+ * sgmcmc_linear_row_groups(n) partial slabs [group][out_features][in_features] (may be NULL), one per group of 16
+ * batch rows, for sgmcmc_wrw_reduce_many (fixed order). */
+int sgmcmc_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int n, int in_features,
+                      int out_features, void* stream);
+int sgmcmc_linear_row_groups(int n);
+int sgmcmc_linear_bwd(const float* x, const float* weight, const float* dy, float* dx, float* dweight_slabs,
+                      float* dbias, int n, int in_features, int out_features, void* stream);
 
 /* Minibatch gather from an HBM-resident image set with random crop (zero padding `pad`) and horizontal flip
  * applied on the way -- the `cifar10_augmented` pipeline (data/CIFAR/cifar.py:136-172: RandomCrop(32,

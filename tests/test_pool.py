@@ -133,3 +133,30 @@ def test_softmax_cross_entropy_matches_aten(b, k, reduction):
     assert pool.cross_entropy(big, torch.zeros(2000, dtype=torch.int64, device="cuda")).item() == pytest.approx(2.302585, rel=1e-5)
     with pytest.raises(ValueError):
         pool.cross_entropy(logits, y, "none")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,j,k,with_bias", [(128, 2450, 10, True), (5, 2450, 10, False), (1, 7, 1, True), (128, 50, 16, True)])
+def test_narrow_linear_matches_float64(n, j, k, with_bias):
+    "the convolutional classifier's head Linear(2450, 10) (models/conv_nets.py:57-70) and other narrow shapes"
+    g = torch.Generator().manual_seed(n + j + k)
+    x, w = torch.randn(n, j, generator=g), torch.randn(k, j, generator=g) / j ** .5
+    b = torch.randn(k, generator=g) if with_bias else None
+    dy = torch.randn(n, k, generator=g)
+    assert pool.linear_supported(x.cuda(), w.cuda(), None if b is None else b.cuda())
+    assert not pool.linear_supported(x, w, b) and not pool.linear_supported(x.cuda(), torch.zeros(17, j).cuda(), None)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if with_bias else None
+    ref = F.linear(xr, wr, br)
+    ref.backward(dy.double())
+    xg, wg = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    bg = b.cuda().requires_grad_() if with_bias else None
+    y = pool.linear(xg, wg, bg)
+    y.backward(dy.cuda())
+    torch.testing.assert_close(y.double().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xg.grad.double().cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(wg.grad.double().cpu(), wr.grad, rtol=1e-5, atol=2e-6 * n ** .5)
+    if with_bias:
+        torch.testing.assert_close(bg.grad.double().cpu(), br.grad, rtol=1e-5, atol=2e-6 * n ** .5)
+    y2 = pool.linear(xg, wg, bg)
+    assert torch.equal(y2, y)
