@@ -332,6 +332,9 @@ def main():
     from bnn_priors_amd.storage import MemoryMetrics
 
     name, xshape, N, prior = WORKLOADS[args.workload]
+    hmc = args.inference == "HMCReject"
+    if hmc and args.trajectory:
+        N = 128 * args.trajectory          # BASELINE configs[4]: a synthetic set of L batches, epoch = trajectory = L steps
     L = -(-N // 128)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     model = make_model(args.workload, device)
@@ -341,13 +344,15 @@ def main():
     pool = PoolSource(args.workload, N, device, 1234 + rank)   # the whole synthetic data set, in HBM
     loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
-    hmc = args.inference == "HMCReject"
     extra = {}
     if hmc and args.trajectory:
         extra["trajectory_length"] = args.trajectory
+    if hmc and args.temperature != 1.0:
+        extra["tempered"] = True           # T != 1 extends the reference's HMC (mcmc/hmc.py:39)
     runner = runner_class(args.inference)(
         model=model, dataloader=loader, dataloader_test=empty_test, epochs_per_cycle=50,
-        warmup_epochs=50 if hmc else 45, sample_epochs=0 if hmc else 5, learning_rate=0.01 if not hmc else 1e-4,
+        warmup_epochs=50 if hmc else 45, sample_epochs=0 if hmc else 5,
+        learning_rate=0.01 if not hmc else 1e-4 * args.temperature,
         skip=1, metrics_skip=args.metrics_skip, temperature=args.temperature, momentum=1.0 if hmc else 0.994,
         sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
         model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank, **extra)

@@ -81,6 +81,42 @@ class VerletSGLDRunnerReject(SGLDRunner):
         fn = getattr(self.optimizer, "delta_energy_of_last_transition", self.optimizer.delta_energy)
         return fn(self._initial_potential, potential)
 
+    def _after_leapfrog(self, step, acc, batches, last_of_epoch):
+        "hook for runners that end trajectories inside an epoch (HMCRunnerReject(trajectory_length=L))"
+        return step
+
+    def _mh_point(self, step, acc, batches, save=None):
+        """End of a trajectory: exact full-data gradient, ``final_step``, energy difference, Metropolis-Hastings
+        test, metrics row; with ``save = (cycle, epoch)`` also evaluation + stored sample; then the momentum
+        refresh (HMC) and the ``initial_step`` of the next trajectory on the same gradient with the next learning
+        rate (inference_reject.py:115-157).  Consumes one step index (quirk 6).  Returns the step counter."""
+        opt = self.optimizer
+        step += 1                                                    # quirk 6
+        loss, log_prior, potential = self._exact_model_potential_and_grad(batches)
+        opt.final_step(calc_metrics=True)
+        delta_energy = _f(self._delta_energy(potential))
+        self._total_energy += delta_energy
+        self._initial_potential = potential.item()                   # quirk 1
+        rejected = False
+        if self.reject_samples:
+            rejected, _ = opt.maybe_reject(delta_energy)
+        self._check_finite()
+        self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
+                           potential=potential.item(), acc=_f(acc),  # quirk 5
+                           lr=opt.param_groups[0]["lr"],
+                           corresponds_to_sample=save is not None, delta_energy=delta_energy,
+                           total_energy=self._total_energy, rejected=rejected)
+        if save is not None:
+            state_dict = self.model.state_dict()
+            self._evaluate_model(state_dict, step)
+            self._save_sample(state_dict, save[0], save[1], step)
+        self.scheduler.step()
+        # first step of the next trajectory: same gradient, next learning rate (:152-157)
+        if _is_hmc(opt):
+            opt.sample_momentum()
+        opt.initial_step(calc_metrics=False, save_state=self.reject_samples)
+        return step
+
     def begin(self):
         """optimizer, scheduler, exact initial gradient, momentum draw and the first
         ``initial_step`` (inference_reject.py:36-66); returns the step counter (0)."""
@@ -128,32 +164,11 @@ class VerletSGLDRunnerReject(SGLDRunner):
                     for i, (x, y) in enumerate(self._hot_batches()):
                         step += 1
                         acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
+                        step = self._after_leapfrog(step, acc, batches, last_of_epoch=(i == n_batches - 1))
 
                     self._drain_rows()
                     if self._is_sampling_epoch(epoch):
-                        step += 1                                                    # quirk 6
-                        loss, log_prior, potential = self._exact_model_potential_and_grad(batches)
-                        opt.final_step(calc_metrics=True)
-                        delta_energy = _f(self._delta_energy(potential))
-                        self._total_energy += delta_energy
-                        self._initial_potential = potential.item()                   # quirk 1
-                        rejected = False
-                        if self.reject_samples:
-                            rejected, _ = opt.maybe_reject(delta_energy)
-                        self._check_finite()
-                        self.store_metrics(i=step, loss=loss.item(), log_prior=log_prior.item(),
-                                           potential=potential.item(), acc=_f(acc),  # quirk 5
-                                           lr=opt.param_groups[0]["lr"],
-                                           corresponds_to_sample=True, delta_energy=delta_energy,
-                                           total_energy=self._total_energy, rejected=rejected)
-                        state_dict = self.model.state_dict()
-                        self._evaluate_model(state_dict, step)
-                        self._save_sample(state_dict, cycle, epoch, step)
-                        self.scheduler.step()
-                        # first step of the next epoch: same gradient, next learning rate (:152-157)
-                        if _is_hmc(opt):
-                            opt.sample_momentum()
-                        opt.initial_step(calc_metrics=False, save_state=self.reject_samples)
+                        step = self._mh_point(step, acc, batches, save=(cycle, epoch))
                     else:
                         self._evaluate_model(self.model.state_dict(), step)
                         self.scheduler.step()
@@ -167,17 +182,49 @@ class VerletSGLDRunnerReject(SGLDRunner):
 
 
 class HMCRunnerReject(VerletSGLDRunnerReject):
+    """inference_reject.py:182-189, plus two keyword-only EXTENSIONS for BASELINE.json configs[4] (the reference has
+    neither: its trajectories are one epoch long and mcmc/hmc.py:39 asserts T == 1):
+
+    ``trajectory_length=L``: a trajectory ends -- exact gradient, ``final_step``, M-H test, momentum refresh,
+    ``initial_step`` -- after every L leapfrog steps as well as at the end of every sampling epoch (where the sample
+    is stored, as in the reference).  Intra-epoch M-H points log a metrics row with ``acceptance/is_sample = 0``.
+    ``tempered=True``: allows ``temperature != 1`` (samples exp(-U/T); see mcmc/hmc.py here)."""
+
+    def __init__(self, *a, trajectory_length=None, tempered=False, **kw):
+        super().__init__(*a, **kw)
+        assert trajectory_length is None or trajectory_length >= 1
+        self.trajectory_length, self.tempered = trajectory_length, tempered
+        self._since_mh = 0
+
     def _make_optimizer(self, params):
         # inference_reject.py:182-189
-        assert self.temperature == 1.0, "HMC only implemented for temperature=1."
+        assert self.tempered or self.temperature == 1.0, "HMC only implemented for temperature=1."
         assert self.momentum == 1.0, "HMC only works with momentum=1."
         assert self.descent_epochs == 0, "HMC not implemented for descent epochs with temp=0."
+        extra = dict(temperature=self.temperature) if self.tempered else {}
         opt = mcmc.HMC(params=params, lr=self.learning_rate, num_data=self.eff_num_data,
-                       **self._sampler_kwargs())
+                       **extra, **self._sampler_kwargs())
         # raise_on_nan keeps the reference's default (True, mcmc/hmc.py:25-27); inside a runner the test is the
         # device-side flag read at metric steps and epoch ends (SGLDRunner._check_finite), not a sync per step
         opt.defer_nan_check = True
         return opt
+
+    def _after_leapfrog(self, step, acc, batches, last_of_epoch):
+        if self.trajectory_length is None:
+            return step
+        self._since_mh += 1
+        if last_of_epoch:
+            # a sampling epoch's end is an M-H point of its own (run()): the count restarts there
+            return step
+        if self._since_mh >= self.trajectory_length:
+            self._since_mh = 0
+            self._drain_rows()
+            step = self._mh_point(step, acc if acc is not None else getattr(self, "_last_acc", 0.), batches)
+        return step
+
+    def _mh_point(self, step, acc, batches, save=None):
+        self._since_mh = 0
+        return super()._mh_point(step, acc, batches, save)
 
 
 class SGLDRunnerReject(VerletSGLDRunnerReject):

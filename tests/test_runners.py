@@ -229,3 +229,56 @@ def test_dense_step_direct_and_graph_replica_modes_are_bit_identical(monkeypatch
         assert np.array_equal(s0[k][0], s1[k][0]) and np.array_equal(s0[k][1], s1[k][1]), k
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: L-step trajectories, T != 1
+def _trajectory_runner(base, T, L, device="cpu"):
+    cfg = RC.CASES["HMCReject"]
+    train, test, (x, y) = RC.make_data(device, cfg=cfg)
+    model = RC.make_net(models, x, y, device=device, cfg=cfg)
+    metrics = MemoryMetrics()
+    torch.manual_seed(RC.SEED)
+    runner = base(model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"] * T,
+                  temperature=T, momentum=1.0, reject_samples=True, metrics_saver=metrics, model_saver=None,
+                  trajectory_length=L, tempered=(T != 1.0), cycle_seed=RC.CYCLE_SEED, **RC.RUN_KW)
+    return runner, metrics
+
+
+def _check_trajectory_streams(metrics, runner, L):
+    got = RC.streams_of(metrics)
+    steps, rej = got["acceptance/rejected"]
+    _, is_sample = got["acceptance/is_sample"]
+    s_all, _ = got["acceptance/is_sample"]
+    # 2 cycles x 2 epochs x 8 minibatches, L = 3: inside a cycle a trajectory ends after leapfrog steps 3, 6, 9, 12, 15
+    # (the count runs across the non-sampling epoch's end) and at the end of the sampling epoch (step 16), where the
+    # count restarts; every M-H point consumes a step index (quirk 6): rows at 0 | 4 8 12 16 20 22 | 26 30 34 38 42 44
+    assert steps.tolist() == [0, 4, 8, 12, 16, 20, 22, 26, 30, 34, 38, 42, 44] and set(rej.tolist()) <= {0, 1}
+    sample_rows = s_all[is_sample == 1]
+    assert len(sample_rows) == 1 + 2                       # the begin() row + one per sampling epoch
+    samples = runner.get_samples()
+    first = next(iter(k for k in samples if k.endswith("weight_prior.p")))
+    assert samples[first].shape[0] == 2
+    de_s, de = got["delta_energy"]
+    assert np.isfinite(de).all()
+
+
+def test_hmc_trajectory_length_host_logic():
+    "HMCRunnerReject(trajectory_length=3): the M-H schedule, with the oracle's sampler plugged in (CPU)"
+    runner, metrics = _trajectory_runner(_with_oracle_sampler(inference_reject.HMCRunnerReject), 1.0, 3)
+    runner.run()
+    _check_trajectory_streams(metrics, runner, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1.0, 0.1])
+def test_hmc_trajectories_and_temperature_on_gpu(T):
+    """the extension end to end on the HIP path: L-step trajectories, tempered acceptance; the kinetic
+    temperature logged right after each momentum refresh estimates T"""
+    runner, metrics = _trajectory_runner(inference_reject.HMCRunnerReject, T, 3, device="cuda:0")
+    runner.run()
+    _check_trajectory_streams(metrics, runner, 3)
+    assert runner.optimizer.param_groups[0]["temperature"] == T
+    with pytest.raises(AssertionError):                    # without tempered=True the reference's assertion stands
+        r2, _ = _trajectory_runner(inference_reject.HMCRunnerReject, 0.5, 3, device="cuda:0")
+        r2.tempered = False
+        r2.run()
