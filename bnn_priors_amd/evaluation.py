@@ -13,6 +13,7 @@ each rank reduces its own samples to (max_e, sum_e exp(x - max)) and two small
 all-reduces (MAX, SUM) over RCCL combine the chains -- N_test*(C+1) doubles,
 instead of gathering [E, N, C] from every GPU.
 """
+import contextlib
 import math
 
 import torch
@@ -34,6 +35,64 @@ def _n_samples(samples):
     return min(len(v) for v in samples.values())
 
 
+BATCHED = True          # stack the samples and run ONE grouped forward per test batch (classification models)
+SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation memory at E_group * batch images
+
+
+@contextlib.contextmanager
+def _plain_torch_layers():
+    """torch.func.vmap batches ATen operators, not this package's custom-kernel autograd functions: inside the
+    grouped forward the layers take their ATen route (the grouped evaluation is a throughput problem -- E samples x
+    a test batch per launch -- that the library's batched convolutions / GEMMs handle well)."""
+    from . import bn, conv, pool, resblock
+    mods = (bn, conv, pool, resblock)
+    old = [m.ENABLED for m in mods]
+    for m in mods:
+        m.ENABLED = False
+    try:
+        yield
+    finally:
+        for m, v in zip(mods, old):
+            m.ENABLED = v
+
+
+@torch.no_grad()
+def _predictive_tables_batched(model, dataloader_test, samples, labels, E, C):
+    """All samples at once (reference semantics: exp_utils.py:250-340, one load_state_dict + one pass over the test
+    set PER SAMPLE): the stored samples stay stacked [E, ...], ``torch.func.functional_call`` under ``vmap`` runs the
+    network once per test batch for a whole group of samples, and the normalisation (log-softmax), the gather of
+    log p(y|x) and the fp64 tables are filled on the device without a Python loop over samples."""
+    from torch.func import functional_call, vmap
+    device = labels.device
+    N = labels.shape[0]
+    lps = torch.zeros((E, N), dtype=torch.float64, device=device)
+    acc = torch.zeros((E, N, C), dtype=torch.float64, device=device)
+    names = set(dict(model.named_parameters())) | set(dict(model.named_buffers()))
+    state = {k: v[:E].to(device) for k, v in samples.items() if k in names}
+    if set(state) != names:
+        raise KeyError("samples do not cover the model's state")
+    temp = model.softmax_temp
+    if callable(temp) or isinstance(temp, torch.Tensor):
+        raise TypeError("batched evaluation needs a plain-number softmax temperature")
+
+    def logits_of(st, x):
+        return functional_call(model.net, {k[len("net."):]: v for k, v in st.items()}, (x,))
+    grouped = vmap(logits_of, in_dims=(0, None), randomness="error")
+    with _plain_torch_layers():
+        i = 0
+        for bx, by in dataloader_test:
+            bx, by = bx.to(device), by.to(device)
+            j = i + len(bx)
+            for e0 in range(0, E, SAMPLE_GROUP):
+                e1 = min(E, e0 + SAMPLE_GROUP)
+                f = grouped({k: v[e0:e1] for k, v in state.items()}, bx)               # [e, B, C]
+                logp = torch.log_softmax(f / temp, dim=-1)        # Categorical(logits=...).logits, in the net's dtype
+                acc[e0:e1, i:j] = logp
+                lps[e0:e1, i:j] = logp.gather(-1, by.view(1, -1, 1).expand(e1 - e0, -1, 1)).squeeze(-1)
+            i = j
+    return lps, acc
+
+
 @torch.no_grad()
 def predictive_tables(model, dataloader_test, samples):
     """lps [E, N] and acc_data [E, N, C] (float64, on the model's device)."""
@@ -42,6 +101,14 @@ def predictive_tables(model, dataloader_test, samples):
     N = labels.shape[0]
     C = int(labels.max().item()) + 1 if labels.dim() == 1 else labels.shape[1]
     E = _n_samples(samples)
+    from .models.base import ClassificationModel
+    if (BATCHED and E > 1 and isinstance(model, ClassificationModel) and labels.dim() == 1
+            and not model.training and device.type == "cuda"):
+        try:
+            lps, acc = _predictive_tables_batched(model, dataloader_test, samples, labels, E, C)
+            return lps, acc, labels, "cat"
+        except (RuntimeError, NotImplementedError, KeyError, TypeError):
+            pass            # an operator without a batching rule, odd state: sample by sample below
     lps = torch.zeros((E, N), dtype=torch.float64, device=device)
     acc = torch.zeros((E, N, C), dtype=torch.float64, device=device)
     kind = None

@@ -1,0 +1,64 @@
+"""Posterior-predictive evaluation (reference bnn_priors/exp_utils.py:250-340): the grouped
+multi-sample path -- all stored samples stacked, one vmapped forward per test batch, fp64 log-mean-exp on the device
+-- against the sample-by-sample statement of the reference's loop, for the three BASELINE networks."""
+import numpy as np
+import pytest
+import torch
+
+from bnn_priors_amd import evaluation as ev
+from bnn_priors_amd import models
+
+
+def _setup(name, n=96, E=5, device="cpu"):
+    torch.manual_seed(0)
+    x = torch.rand(n, 3, 32, 32) if name == "googleresnet" else torch.rand(n, 784)
+    y = torch.arange(n) % 10
+    net = models.get_model(x, y, name, width=50, depth=3, weight_prior="gaussian", weight_loc=0., weight_scale=2 ** .5,
+                           bias_prior="gaussian", bias_loc=0., bias_scale=1., batchnorm=True, weight_prior_params={},
+                           bias_prior_params={})
+    models.he_initialize(net)
+    net = net.to(device).eval()
+    g = torch.Generator().manual_seed(1)
+    samples = {}
+    for k, v in net.state_dict().items():
+        if v.is_floating_point():
+            noise = 0.05 * torch.randn((E,) + tuple(v.shape), generator=g).to(device)
+            samples[k] = (v.unsqueeze(0) + noise * v.abs().mean()).clone()
+            if k.endswith("running_var"):
+                samples[k] = samples[k].abs() + 0.5
+        else:
+            samples[k] = v.unsqueeze(0).repeat((E,) + (1,) * v.dim())
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x.to(device), y.to(device)), batch_size=32)
+    return net, loader, samples, y
+
+
+@pytest.mark.parametrize("name", ["classificationdensenet", "classificationconvnet", "googleresnet"])
+def test_grouped_tables_equal_the_per_sample_loop_cpu(name):
+    net, loader, samples, y = _setup(name)
+    lps_b, acc_b = ev._predictive_tables_batched(net, loader, samples, y, 5, 10)
+    old = ev.BATCHED
+    ev.BATCHED = False
+    try:
+        lps, acc, _, kind = ev.predictive_tables(net, loader, samples)
+    finally:
+        ev.BATCHED = old
+    assert kind == "cat"
+    torch.testing.assert_close(lps_b, lps, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(acc_b, acc, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["classificationdensenet", "classificationconvnet", "googleresnet"])
+def test_grouped_evaluation_on_gpu_matches_the_loop_and_is_taken(name, monkeypatch):
+    net, loader, samples, y = _setup(name, device="cuda:0")
+    used = []
+    real = ev._predictive_tables_batched
+    monkeypatch.setattr(ev, "_predictive_tables_batched", lambda *a: (used.append(1), real(*a))[1])
+    got = ev.evaluate_model(net, loader, samples)
+    assert used                                             # the grouped path ran (and did not fall back)
+    monkeypatch.setattr(ev, "BATCHED", False)
+    want = ev.evaluate_model(net, loader, samples)          # this repo's kernels, sample by sample
+    for k in want:
+        assert got[k] == pytest.approx(want[k], rel=2e-4, abs=2e-4), k
+    from bnn_priors_amd import conv
+    assert conv.ENABLED                                     # the layer switches are restored
