@@ -106,6 +106,14 @@ class MlpArgs(ctypes.Structure):
                 ("grad_scale", ctypes.c_float), ("split_scratch", ctypes.c_void_p)]
 
 
+class DenseChain(ctypes.Structure):
+    "sgmcmc_dense_chain"
+    _fields_ = [("mlp", MlpArgs), ("layout", Layout), ("num_data", ctypes.c_double),
+                ("chain_id", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+MAX_CHAINS, MLP_BATCH_MULTI = 8, 128
+
 EXPORTS = {
     "sgmcmc_abi_version": (ctypes.c_int, []),
     "sgmcmc_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -153,6 +161,9 @@ EXPORTS = {
                                                 ctypes.POINTER(StepArgs), ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.POINTER(StepArgs),
                                                 ctypes.c_void_p]),
+    "sgmcmc_dense_step_multi": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(DenseChain), ctypes.c_int,
+                                               ctypes.POINTER(StepArgs), ctypes.c_void_p, ctypes.POINTER(StepArgs),
+                                               ctypes.c_void_p]),
     "sgmcmc_finalize": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
                                        ctypes.c_void_p]),
     "sgmcmc_accumulate_parts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,

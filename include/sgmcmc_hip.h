@@ -321,6 +321,25 @@ int sgmcmc_dense_step_direct(const sgmcmc_layout* L, const sgmcmc_mlp_args* mlp,
  * update kernel.  If A->flags has SGMCMC_DEFER_FINALIZE this call's own bookkeeping is left
  * pending in turn; otherwise it is launched as usual. */
 
+/* The same three launches for SEVERAL independent chains at once (grid dimension y = chain): chains of one
+ * architecture and one schedule, stepped in lock-step, each with its own weights, data order, sampler arena and
+ * Philox stream (chain_id).  `chains_dev`: device array [n_chains], written once by the caller; `chain0_host`: a
+ * host copy of element 0 (launch geometry); A: the transition's scalars, common to all chains (A->stream is
+ * ignored: every chain draws from ITS stream; A must carry SMALL_FINALIZE and DEFER_FINALIZE); idx_host:
+ * [n_chains][batch] data-set rows (16-bit: data sets of up to 65,536 rows); A_pending as sgmcmc_dense_step_direct.
+ * Chain c's results are bit-identical to the same chain stepped alone by sgmcmc_dense_step_direct. */
+#define SGMCMC_MAX_CHAINS 8
+#define SGMCMC_MLP_BATCH_MULTI 128
+typedef struct {
+  sgmcmc_mlp_args mlp;
+  sgmcmc_layout layout;
+  double num_data;
+  uint32_t chain_id, reserved;
+} sgmcmc_dense_chain;
+int sgmcmc_dense_step_multi(const sgmcmc_dense_chain* chains_dev, const sgmcmc_dense_chain* chain0_host, int n_chains,
+                            const sgmcmc_step_args* A, const uint16_t* idx_host, const sgmcmc_step_args* A_pending,
+                            void* stream);
+
 /* The per-segment bookkeeping of a transition that was launched with SGMCMC_DEFER_FINALIZE. */
 int sgmcmc_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* stream);
 
