@@ -81,6 +81,8 @@ def parse():
                     help="HMCReject only: leapfrog steps per trajectory (BASELINE configs[4]: 50); 0 = one epoch")
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
+    ap.add_argument("--chain-sweep", default="1,2,4,8",
+                    help="densenet only: aggregate steps/s of K chains sharing ONE GPU's launches (MultiChainDense); '' = skip")
     return ap.parse_args()
 
 
@@ -236,6 +238,57 @@ def flat_arena_point(log2n, device, iters=20):
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 traffic=None, algorithmic_bytes_per_launch=BYTES_PER_PARAM * n, elements=n,
                 avg_kernel_ms=round(avg_ms, 4), min_kernel_ms=round(min(times), 4), launches=len(times))
+
+
+# ------------------------------------------------------------------ several chains per GPU (the small nets)
+def chains_per_gpu_sweep(args, device, rank, ks, steps=600, warmup=60):
+    """K independent chains of the dense classifier on ONE GPU, stepped in lock-step by three launches per step
+    (fused_dense.MultiChainDense): aggregate leapfrog steps/s = K * steps / time, per K.  Every chain has its own
+    model, synthetic data (seed 1234 + chain), sampler arena and Philox stream; metric read-back every 10th step."""
+    from bnn_priors_amd.fused_dense import MultiChainDense
+    from bnn_priors_amd.inference_reject import runner_class
+    from bnn_priors_amd.storage import MemoryMetrics
+    import numpy as np
+    name, xshape, N, prior = WORKLOADS["densenet"]
+    runners, pools = [], []
+    for c in range(max(ks)):
+        model = make_model("densenet", device)
+        pool = PoolSource("densenet", N, device, 1234 + 8 * rank + c)
+        loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
+        empty = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
+        r = runner_class("VerletSGLDReject")(
+            model=model, dataloader=loader, dataloader_test=empty, epochs_per_cycle=50, warmup_epochs=45,
+            sample_epochs=5, learning_rate=0.01, skip=1, metrics_skip=args.metrics_skip, temperature=1.0,
+            momentum=0.994, sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
+            model_saver=None, reject_samples=True, seed=1234, chain_id=8 * rank + c)
+        r._batch_source = pool
+        r.begin()
+        runners.append(r)
+        pools.append(pool)
+    out = {}
+    nb = N // 128
+    for K in sorted(ks, reverse=True):      # largest first: the chains of a smaller K have advanced together so far
+        multi = MultiChainDense([r._fused_dense() for r in runners[:K]])
+        idx = [[np.arange(128 * ((t + 7 * c) % nb), 128 * ((t + 7 * c) % nb) + 128, dtype=np.int64) for c in range(K)]
+               for t in range(64)]
+
+        def run(n, t0):
+            for t in range(t0, t0 + n):
+                multi.step(idx[t % 64], metrics=(t % args.metrics_skip == 0))
+                for r in runners[:K]:
+                    r.scheduler.step()
+            return t0 + n
+        t = run(warmup, 1)
+        torch.cuda.synchronize(device)
+        ts = time.perf_counter()
+        t = run(steps, t)
+        for r in runners[:K]:
+            r.optimizer.engine.flush()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - ts
+        out[str(K)] = {"aggregate_steps_per_s": round(K * steps / dt, 1), "per_chain_steps_per_s": round(steps / dt, 1),
+                       "us_per_lockstep": round(dt / steps * 1e6, 2)}
+    return {k: out[k] for k in sorted(out, key=int)}
 
 
 # ------------------------------------------------------------------ the one exchange of the multi-chain path
@@ -531,6 +584,8 @@ def main():
             out["roofline"] = sampler_line
         if args.sweep_log2:
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
+        if args.workload == "densenet" and args.chain_sweep and args.inference == "VerletSGLDReject":
+            out["chains_per_gpu"] = chains_per_gpu_sweep(args, device, rank, [int(k) for k in args.chain_sweep.split(",")])
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]

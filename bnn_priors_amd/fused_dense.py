@@ -289,3 +289,96 @@ class FusedDenseLeapfrog(_ReportSlots):
         if r["nonfinite"]:
             eng.scalars[1].zero_()
         return r
+
+
+class MultiChainDense:
+    """K independent chains of the dense classifier stepped in lock-step by THREE launches per leapfrog step
+    (``sgmcmc_dense_step_multi``: grid dimension y = chain) instead of 3 K.
+
+    One chain's launches occupy 33-46 workgroups of the 256 CUs and are latency-bound (a step is three dependent
+    launches of 6-12 us whatever the net's size); chains are independent, so K of them -- each with its own
+    ``FusedDenseLeapfrog`` (weights, sampler arena, data order, Philox stream) -- share the launches and the GPU does
+    K steps in about the time of one.  All chains must have one architecture and one schedule (learning rate,
+    temperature, metrics cadence): the transition's scalars travel once, by value.  Chain c's trajectory is
+    bit-identical to the same chain stepped alone (tests/test_fused_dense.py).  This is an addition to the
+    reference's one-process-per-chain model (experiments/run_experiment.sh:15-34), for the small nets only."""
+
+    def __init__(self, steppers):
+        self.steppers = list(steppers)
+        K = len(self.steppers)
+        if not 1 <= K <= _hip.MAX_CHAINS:
+            raise ValueError(f"1..{_hip.MAX_CHAINS} chains per launch")
+        s0 = self.steppers[0]
+        for s in self.steppers:
+            if not (s.direct and s.split and s.eng.small_finalize and s.eng.chunk == _hip.CHUNK_SMALL):
+                raise ValueError("multi-chain stepping needs the direct, split fused dense path")
+            if [tuple(p.shape) for p in s.eng.params] != [tuple(p.shape) for p in s0.eng.params]:
+                raise ValueError("chains must share one architecture")
+            if s.X.shape[0] > 65536:
+                raise ValueError("16-bit row indices: data sets of up to 65,536 rows")
+        self.lib, self.device = s0.lib, s0.eng.device
+        self._host = (_hip.DenseChain * K)()
+        self._dev = torch.zeros(ctypes.sizeof(self._host), dtype=torch.uint8, device=self.device)
+        self._uploaded = None
+        self._idx16 = np.zeros((K, _hip.MLP_BATCH_MULTI), dtype=np.uint16)
+
+    def _table(self, batch):
+        "per-chain pointers, uploaded when any of them changed (first use, roll-back arrays allocated, ...)"
+        for c, s in enumerate(self.steppers):
+            st = s._by_batch.get(batch)
+            if st is None:
+                st = s._by_batch[batch] = s._setup(batch)
+                s._static_flags = st["A"].flags & ~_hip.CALC_METRICS
+            s._bind_grads()
+            if s.eng._seg_dirty or s.eng._precond_dirty:
+                s.eng.refresh(s.opt._preconditioners())
+            row = self._host[c]
+            ctypes.memmove(ctypes.addressof(row.mlp), ctypes.addressof(st["mlp"]), ctypes.sizeof(_hip.MlpArgs))
+            ctypes.memmove(ctypes.addressof(row.layout), ctypes.addressof(s.eng.layout), ctypes.sizeof(_hip.Layout))
+            row.num_data, row.chain_id = float(s.pot.N), int(s.eng.chain_id)
+        raw = bytes(self._host)
+        if raw != self._uploaded:
+            self._dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))     # synchronous: rare
+            self._uploaded = raw
+
+    def step(self, idx_list, metrics=False):
+        """one leapfrog step of every chain on ITS rows ``idx_list[c]`` (host int arrays of one length <= 128).
+        ``metrics``: the transition also updates the temperature estimates / log-prior; returns one
+        dict(loss, acc, log_prior, energy, nonfinite) per chain (after one read-back each), else None."""
+        K, batch = len(self.steppers), len(idx_list[0])
+        if batch > _hip.MLP_BATCH_MULTI or any(len(i) != batch for i in idx_list):
+            raise ValueError("one batch size of at most 128 rows for all chains")
+        self._table(batch)
+        s0 = self.steppers[0]
+        st0 = s0._by_batch[batch]
+        s0._pp ^= 1
+        A = s0._args(st0["App"][s0._pp], metrics)
+        A.flags |= _hip.DEFER_FINALIZE
+        for s in self.steppers[1:]:
+            d = s.eng.next_draw()
+            if d != A.draw or s.opt.param_groups[0]["lr"] != s0.opt.param_groups[0]["lr"]:
+                raise RuntimeError("chains stepped together must share the schedule and the draw counter")
+        for c, idx in enumerate(idx_list):
+            self._idx16[c, :batch] = idx
+        pending = s0.eng.pending
+        idx16 = np.ascontiguousarray(self._idx16[:, :batch])
+        err = self.lib.sgmcmc_dense_step_multi(self._dev.data_ptr(), ctypes.byref(self._host[0]), K, A,
+                                               idx16.ctypes.data, pending, s0.eng.stream())
+        if err:
+            _hip.check(err, "sgmcmc_dense_step_multi")
+        for s in self.steppers:
+            s.eng.pending = A
+            s.eng._state_host = None
+            s.eng.energy_ready = True
+        if not metrics:
+            return None
+        out = []
+        for s in self.steppers:
+            eng = s.eng
+            eng.flush()                      # this chain's bookkeeping, now (the row reads its results)
+            eng.metrics_ready = True
+            v = eng.report.cpu().numpy()
+            out.append(dict(loss=float(v[4]), acc=float(v[5]), nonfinite=bool(v[1] != 0.0), log_prior=float(v[2]),
+                            energy=float(v[3])))
+            eng._state_host = v[8:].reshape(eng.n_seg, -1).copy()
+        return out

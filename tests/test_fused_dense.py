@@ -116,3 +116,86 @@ def test_fused_exact_gradient_pass_matches_autograd():
     for a, b in zip(got, want):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 3e-6 * scale + 1e-10
+
+
+def _chain(seed, chain_id, n_data=2000):
+    "a runner of the BASELINE dense classifier on its own synthetic device-resident set, ready to leapfrog"
+    import runner_cases as RC
+    from bnn_priors_amd import inference_reject, models
+    from bnn_priors_amd.storage import MemoryMetrics
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n_data, 784, generator=g).to(DEV)
+    y = torch.randint(0, 10, (n_data,), generator=g).to(DEV)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=128, shuffle=True)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:0], y[:0]), batch_size=128)
+    torch.manual_seed(seed)
+    model = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "classificationdensenet", width=50, depth=3,
+                             weight_prior="gaussian", weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
+    models.he_initialize(model)
+    model = model.to(DEV)
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, learning_rate=0.01, temperature=1.0, momentum=0.994,
+        metrics_saver=MemoryMetrics(), seed=99, chain_id=chain_id, epochs_per_cycle=2, warmup_epochs=1,
+        sample_epochs=1, skip=1, metrics_skip=10, cycles=1, precond_update=1, sampling_decay="cosine")
+    runner.begin()
+    return runner
+
+
+def _snapshot(runner):
+    opt = runner.optimizer
+    return ([p.detach().clone() for p in runner._params],
+            [opt.state[p]["momentum_buffer"].clone() for p in runner._params],
+            [opt.state[p]["square_avg"].clone() for p in runner._params])
+
+
+def test_chains_stepped_together_are_bit_identical_to_chains_stepped_alone():
+    """sgmcmc_dense_step_multi (grid dimension y = chain): 3 chains with their own weights, data, Philox streams --
+    after 25 lock-step leapfrog steps every chain's theta / m / v and its metric row equal, bit for bit, the same
+    chain stepped alone through the single-chain direct path"""
+    from bnn_priors_amd.fused_dense import MultiChainDense
+    K, steps = 3, 25
+    g = np.random.default_rng(5)
+    idx = [[g.choice(2000, 128, replace=False).astype(np.int64) for _ in range(K)] for _ in range(steps)]
+
+    alone, rows_alone = [], []
+    for c in range(K):
+        r = _chain(10 + c, c)
+        f = r._fused_dense()
+        assert f is not None and f.direct and f.split
+        row = None
+        for t in range(steps):
+            out = f.replay(idx[t][c], metrics=(t % 10 == 9))
+            row = out or row
+            r.scheduler.step()
+        r.optimizer.engine.flush()
+        alone.append(_snapshot(r))
+        rows_alone.append(row)
+
+    runners = [_chain(10 + c, c) for c in range(K)]
+    multi = MultiChainDense([r._fused_dense() for r in runners])
+    rows = None
+    for t in range(steps):
+        out = multi.step(idx[t], metrics=(t % 10 == 9))
+        rows = out or rows
+        for r in runners:
+            r.scheduler.step()
+    for r in runners:
+        r.optimizer.engine.flush()
+    for c, r in enumerate(runners):
+        for a, b in zip(_snapshot(r), alone[c]):
+            for u, v in zip(a, b):
+                assert torch.equal(u, v), f"chain {c}"
+        for k in ("loss", "acc", "log_prior", "energy"):
+            assert rows[c][k] == rows_alone[c][k], (c, k)
+    # different chains did different things
+    assert not torch.equal(_snapshot(runners[0])[0][0], _snapshot(runners[1])[0][0])
+    # and a single-chain "batch" works too
+    one = _chain(10, 0)
+    m1 = MultiChainDense([one._fused_dense()])
+    for t in range(steps):
+        m1.step([idx[t][0]], metrics=(t % 10 == 9))
+        one.scheduler.step()
+    one.optimizer.engine.flush()
+    for a, b in zip(_snapshot(one), alone[0]):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
