@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")]
 SOURCE = SOURCES[0]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CHUNK = 4096
 CHUNK_SMALL = 1024
 NSUMS = 6
@@ -73,7 +73,7 @@ class StepArgs(ctypes.Structure):
 class ReduceJob(ctypes.Structure):
     "sgmcmc_reduce_job"
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_slabs", ctypes.c_int32),
-                ("numel", ctypes.c_int32)]
+                ("numel", ctypes.c_int32), ("taps", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class ConvBnBwdArgs(ctypes.Structure):

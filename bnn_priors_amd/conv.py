@@ -121,7 +121,7 @@ def _both_grads(x, w, dy, defer):
     if defer:
         # autograd gets an ALIAS: AccumulateGrad only adopts a gradient nobody else references, and it
         # must adopt (not copy) this one -- its memory is filled at the end of the pass
-        _pending.append((scratch, dw, slabs.value))
+        _pending.append((scratch, dw, slabs.value, 9))     # 3x3 slabs are tap-major (sgmcmc_reduce_job.taps)
         return dx, dw.view(dw.shape)
     return dx, dw
 
@@ -135,8 +135,8 @@ def _flush_pending():
     if not _pending:
         return
     jobs = (_hip.ReduceJob * len(_pending))()
-    for j, (scratch, dw, slabs) in zip(jobs, _pending):
-        j.part, j.out, j.n_slabs, j.numel = scratch.data_ptr(), dw.data_ptr(), slabs, dw.numel()
+    for j, (scratch, dw, slabs, taps) in zip(jobs, _pending):
+        j.part, j.out, j.n_slabs, j.numel, j.taps = scratch.data_ptr(), dw.data_ptr(), slabs, dw.numel(), taps
     err = _hip.lib().sgmcmc_wrw_reduce_many(ctypes.cast(jobs, ctypes.c_void_p), len(_pending), _stream())
     _pending.clear()
     if err:
@@ -246,8 +246,8 @@ class _ConvDown(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv_down_bwd")
         if defer:   # scratch = [slabs][dwm.numel()] then [slabs][dws.numel()]
-            _pending.append((scratch, dwm, slabs.value))
-            _pending.append((scratch[slabs.value * dwm.numel():], dws, slabs.value))
+            _pending.append((scratch, dwm, slabs.value, 9))
+            _pending.append((scratch[slabs.value * dwm.numel():], dws, slabs.value, 1))
             return dx, dwm.view(dwm.shape), dws.view(dws.shape), None
         return dx, dwm, dws, None
 
@@ -308,7 +308,7 @@ class _ConvStem(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv_stem_wrw")
         if defer:
-            _pending.append((scratch, dw, slabs.value))
+            _pending.append((scratch, dw, slabs.value, 1))
             return None, dw.view(dw.shape), None
         return None, dw, None
 
@@ -360,7 +360,7 @@ class _ConvFirst(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv_first_wrw")
         if defer:
-            _pending.append((scratch, dw, slabs.value))
+            _pending.append((scratch, dw, slabs.value, 1))
             return None, dw.view(dw.shape)
         return None, dw
 
@@ -417,7 +417,7 @@ class _Conv50(torch.autograd.Function):
         if err:
             _hip.check(err, "sgmcmc_conv50_bwd")
         if defer:
-            _pending.append((scratch, dw, slabs.value))
+            _pending.append((scratch, dw, slabs.value, 9))
             return dx, dw.view(dw.shape)
         return dx, dw
 

@@ -59,7 +59,7 @@ class _BiasReluPool(torch.autograd.Function):
         if _conv._may_defer(bias):
             # summed with the convolutions' weight-gradient slabs at the end of the backward pass
             torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
-            _conv._pending.append((part, db, part.shape[0]))
+            _conv._pending.append((part, db, part.shape[0], 1))
             return dx, db.view(db.shape)
         job = (_hip.ReduceJob * 1)()
         job[0].part, job[0].out, job[0].n_slabs, job[0].numel = part.data_ptr(), db.data_ptr(), part.shape[0], c
@@ -89,7 +89,7 @@ def _reduce_rows(slabs, out, defer):
     import ctypes
     if defer:
         torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
-        _conv._pending.append((slabs, out, slabs.shape[0]))
+        _conv._pending.append((slabs, out, slabs.shape[0], 1))
         return out.view(out.shape)
     job = (_hip.ReduceJob * 1)()
     job[0].part, job[0].out, job[0].n_slabs, job[0].numel = slabs.data_ptr(), out.data_ptr(), slabs.shape[0], out.numel()

@@ -82,10 +82,10 @@ def _reduce_or_defer(lib, w, part, n_slabs, s):
     dw = torch.empty_like(w)
     if _conv._may_defer(w):      # summed with the pass's other slabs by ONE launch at its end
         torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
-        _conv._pending.append((part, dw, n_slabs))
+        _conv._pending.append((part, dw, n_slabs, 9))
         return dw.view(dw.shape)
     job = (_hip.ReduceJob * 1)()
-    job[0].part, job[0].out, job[0].n_slabs, job[0].numel = part.data_ptr(), dw.data_ptr(), n_slabs, dw.numel()
+    job[0].part, job[0].out, job[0].n_slabs, job[0].numel, job[0].taps = part.data_ptr(), dw.data_ptr(), n_slabs, dw.numel(), 9
     err = lib.sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, s)
     if err:
         _hip.check(err, "sgmcmc_wrw_reduce_many")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 3
+#define SGMCMC_ABI_VERSION 4
 #define SGMCMC_CHUNK 4096 /* default elements per arena chunk = 256 threads x 4 items x 4 elements */
 #define SGMCMC_CHUNK_SMALL 1024 /* small models: one item per thread, 4x more workgroups */
 #define SGMCMC_NSUMS 6
@@ -383,6 +383,9 @@ typedef struct sgmcmc_reduce_job {
   const float* part; /* [n_slabs][numel] */
   float* out;        /* [numel] */
   int32_t n_slabs, numel;
+  int32_t taps;      /* <= 1: out[j] = sum_p part[p][j].  > 1: the slabs are TAP-MAJOR ([taps][numel / taps], what the 3x3
+                      * weight-gradient kernels write: coalesced) and out is [numel / taps][taps] = [co][ci][r,s] */
+  int32_t reserved;
 } sgmcmc_reduce_job;
 int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
                        float* scratch, int n_img, int channels, int hw, int* deferred_slabs, void* stream);

@@ -50,6 +50,14 @@ def algorithmic_bytes(name, grid):
         act = 4 * n * c * hw * hw
         slabs = n * (hw // 8) // 2
         return 2 * act + 36 * c * c, act + 36 * c * c * slabs       # reads x, dy, w; writes dx + partial slabs
+    m = re.search(r"fused_bwd_kernel<(\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        c, hw = int(m.group(1)), int(m.group(2))
+        n = grid // 256 * 2 // (3 * (hw // 8) * (c // 16))
+        act = 4 * n * c * hw * hw
+        slabs = n * (hw // 8) // 2
+        extra = 2 * act if m.group(4) == "true" else 0              # the shortcut's dout / out in the epilogue
+        return 4 * act + 36 * c * c + extra, act + 36 * c * c * slabs   # reads x, dout, out, y, w; writes dx + slabs
     return None
 
 
