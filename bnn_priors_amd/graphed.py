@@ -32,6 +32,37 @@ from . import pool as _pool
 from . import _hip
 
 
+def _stageable(dst, src):
+    return (src.is_cuda and src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous()
+            and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0 and (dst.numel() * dst.element_size()) % 4 == 0)
+
+
+def stage_batch(x_dst, x, y_dst, y, args_dst=None, args_pinned=None):
+    """x_dst <- x, y_dst <- y (and the argument block from its pinned slot) in one launch when the batch is a
+    contiguous device tensor of the static inputs' dtype; anything else (a host batch, a strided view, another
+    dtype) goes through ``Tensor.copy_``, which converts."""
+    jobs = []
+    for dst, src in ((x_dst, x), (y_dst, y)):
+        if src is None:
+            continue
+        if _stageable(dst, src):
+            jobs.append((src.data_ptr(), dst.data_ptr(), dst.numel() * dst.element_size()))
+        else:
+            dst.copy_(src)
+    if args_dst is not None:
+        if args_pinned.numel() % 4 == 0:
+            jobs.append((args_pinned.data_ptr(), args_dst.data_ptr(), args_pinned.numel()))
+        else:
+            args_dst.copy_(args_pinned, non_blocking=True)
+    if not jobs:
+        return
+    n = len(jobs)
+    src, dst, nb = (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]), \
+        (ctypes.c_int64 * n)(*[j[2] for j in jobs])
+    _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n, torch.cuda.current_stream(x_dst.device).cuda_stream),
+               "sgmcmc_stage_batch")
+
+
 class PendingRow:
     """A metric step's read-back in flight: one async copy of ``report`` (+ optional head
     scalars) into a pinned slot, guarded by an event.  ``get()`` waits for it and returns
@@ -84,14 +115,16 @@ class GraphedLeapfrog(_ReportSlots):
         self._capture(x_example, y_example, warmup)
 
     # ------------------------------------------------------------------ args ring
-    def _push_args(self, A):
+    def _push_args(self, A, x=None, y=None):
+        """The step's argument block into its device copy through a pinned ring slot -- and, with it, the
+        minibatch into the graph's static inputs: ONE launch (``sgmcmc_stage_batch``) for all three."""
         i = self._k % len(self._slots)
         self._k += 1
         ev = self._slot_events[i]
         if ev is not None:
             ev.synchronize()            # the copy that last used this slot has executed
         ctypes.memmove(self._slots[i].data_ptr(), ctypes.addressof(A), ctypes.sizeof(A))
-        self.args_dev.copy_(self._slots[i], non_blocking=True)
+        stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i])
         ev = self._slot_events[i] = ev or torch.cuda.Event()
         ev.record()
 
@@ -177,8 +210,6 @@ class GraphedLeapfrog(_ReportSlots):
         ``metrics=True``: the transition also updates the temperature estimates and the fused
         log-prior; returns dict(loss, acc, log_prior, energy, nonfinite) of Python floats after ONE
         device->host copy, and primes the engine's per-segment state cache with the same copy."""
-        self.x.copy_(x)
-        self.y.copy_(y)
         eng = self.eng
         if self._bound is not metrics:
             for p, g in zip(eng.params, self.static_grads[metrics]):
@@ -190,7 +221,7 @@ class GraphedLeapfrog(_ReportSlots):
         eng.refresh(self.opt._preconditioners())
         # ``metrics`` picks the graph variant (with accuracy / log-prior / packed read-back);
         # ``calc_metrics`` (default: the same) is the sampler's own flag, read from the args at run time
-        self._push_args(self._args(calc_metrics=metrics if calc_metrics is None else calc_metrics))
+        self._push_args(self._args(calc_metrics=metrics if calc_metrics is None else calc_metrics), x, y)
         self.graphs[metrics].replay()
         eng._touch()
         eng.energy_ready = True
@@ -287,8 +318,7 @@ class GraphedAccumulate:
             p.grad = g
 
     def add(self, x, y):
-        self.x.copy_(x)
-        self.y.copy_(y)
+        stage_batch(self.x, x, self.y, y)
         self.graph.replay()
 
     def add_eager(self, x, y):

@@ -532,6 +532,13 @@ int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, con
                           int channels, int height, int width, int pad, int flip, uint64_t seed,
                           uint32_t stream, uint64_t draw, void* stream_);
 
+/* Up to three plain device copies in ONE launch: dst[j][0 .. bytes[j]) = src[j][...].  For the per-step staging of a
+ * captured step -- the minibatch (x, y) into the graph's static inputs and the argument block from PINNED host
+ * memory (the kernel reads it over the bus) -- which otherwise costs three copy dispatches between two graph
+ * launches.  Pointers 16-byte aligned, sizes multiples of 4; else hipErrorInvalidValue.  No reference counterpart:
+ * the reference's batches arrive from its DataLoader (experiments/train_bnn.py:172-180). */
+int sgmcmc_stage_batch(const void* const* src, void* const* dst, const int64_t* bytes, int n_copies, void* stream);
+
 /* loss = scale * sum_b -log softmax(logits_b)[y_b] for up to 1024 rows of up to 16 classes (the likelihood term of
  * models/base.py:168-191), one launch each way: forward keeps probs [rows][classes] for the backward,
  * dlogits = *grad_out * scale * (probs - onehot(y)).  scale = 1/rows for the minibatch mean, 1/N in the exact

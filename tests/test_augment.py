@@ -152,3 +152,35 @@ def test_kernel_output_obeys_the_reference_pipelines_contract():
     out_b = other.gather(data.cuda(), idx.cuda(), 0).cpu()
     out_a = aug.gather(data.cuda(), idx.cuda(), 0).cpu()
     assert (out_a == out_b).flatten(1).all(1).float().mean().item() < 3.0 / 162
+
+
+@pytest.mark.gpu
+def test_stage_batch_copies_up_to_three_buffers_in_one_launch_bit_exactly():
+    """sgmcmc_stage_batch: minibatch + pinned argument block into a captured step's static inputs; pure data
+    movement, so bit-exact -- including a size that is not a multiple of the 16-byte vector and of the
+    4096-byte block, and a pinned-host source."""
+    import ctypes
+    from bnn_priors_amd import _hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn((128, 3, 32, 32), generator=g, device=dev)
+    y = torch.randint(0, 10, (128,), generator=g, device=dev)
+    args = torch.randint(0, 255, (204,), dtype=torch.uint8).pin_memory()
+    for n in (3, 2, 1):
+        xd, yd, ad = torch.zeros_like(x), torch.zeros_like(y), torch.zeros(204, dtype=torch.uint8, device=dev)
+        srcs, dsts = [x, y, args][:n], [xd, yd, ad][:n]
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+        nb = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in srcs])
+        _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n, torch.cuda.current_stream(dev).cuda_stream), "stage")
+        torch.cuda.synchronize(dev)
+        for s, d in zip(srcs, dsts):
+            assert torch.equal(s.to(dev), d)
+    # rejected: a size that is not a multiple of 4, a misaligned pointer
+    src = (ctypes.c_void_p * 1)(x.data_ptr() + 4)
+    dst = (ctypes.c_void_p * 1)(xd.data_ptr())
+    nb = (ctypes.c_int64 * 1)(64)
+    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, 0) != 0
+    src = (ctypes.c_void_p * 1)(x.data_ptr())
+    nb = (ctypes.c_int64 * 1)(63)
+    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, 0) != 0
