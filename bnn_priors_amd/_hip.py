@@ -30,6 +30,7 @@ VERLET, HMC, SGLD = 0, 1, 2
 INITIAL, FINAL, SAVE_STATE, CALC_METRICS, UNALIGNED, NO_MOMENTUM, SMALL_FINALIZE = 1, 2, 4, 8, 16, 32, 64
 WITH_LOG_PRIOR = 128
 DEFER_FINALIZE = 256
+INLINE_PRIOR = 512
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T, PRIOR_CAUCHY, PRIOR_GENNORM = 0, 1, 2, 3, 4, 5
 PRIOR_GAMMA_SOFTPLUS, PRIOR_UNIFORM_CDF, PRIOR_HALFCAUCHY_SOFTPLUS = 6, 7, 8
 PRIOR_HAS_LINKS, PRIOR_FULL = 1, 2
@@ -203,6 +204,8 @@ EXPORTS = {
     "sgmcmc_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "sgmcmc_augment_gather": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
+    "sgmcmc_softmax_xent_fwd_grad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                    ctypes.c_float, ctypes.c_void_p]),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3
                            + [ctypes.c_void_p]),

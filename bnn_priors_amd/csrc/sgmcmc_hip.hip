@@ -433,7 +433,9 @@ __device__ __forceinline__ void publish_batch_stats(const sgmcmc_layout& L, cons
   }
 }
 
-template <typename T, int KIND, bool VEC, int ITEMS, bool PARTS, bool STREAM = false>
+// PRIOR (without PARTS): g is autograd's gradient of the likelihood term; the closed-form prior gradient is added in
+// flight (SGMCMC_INLINE_PRIOR) instead of by a prior_kernel launch before this one -- as PARTS has always done.
+template <typename T, int KIND, bool VEC, int ITEMS, bool PARTS, bool STREAM = false, bool PRIOR = false>
 __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A,
                                           const GradParts& G) {
   const int64_t chunk = A.chunk_begin + blockIdx.x;
@@ -464,7 +466,8 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   // SGLD's final step modifies nothing (sgld.py:80-85); Verlet/HMC's writes m only.
   const bool write_m = !C.no_mom && !(KIND == SGMCMC_SGLD && C.is_final);
   const bool draw_noise = (KIND != SGMCMC_HMC) && C.has_noise && !(KIND == SGMCMC_SGLD && C.is_final);
-  const bool calc_logp = PARTS && (A.flags & SGMCMC_CALC_METRICS);
+  constexpr bool WITH_PRIOR = PARTS || PRIOR;
+  const bool calc_logp = WITH_PRIOR && (A.flags & SGMCMC_CALC_METRICS);
 
   T* __restrict__ gp = (T*)sp->g + cx.seg_off;
   T* __restrict__ thp = (T*)sp->theta + cx.seg_off;
@@ -476,7 +479,7 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   const uint64_t noise0 = (uint64_t)(sp->noise_base + cx.seg_off);
   const float* __restrict__ pp = PARTS ? G.gpart + sp->noise_base + cx.seg_off : nullptr;
   PriorCoef<T> PC;
-  if (PARTS) PC.template init<false>(L, sp, G.num_data);
+  if (WITH_PRIOR) PC.template init<false>(L, sp, PARTS ? G.num_data : A.num_data);
   double dls_unused = 0.0;
 
   double acc[SGMCMC_NSUMS] = {0, 0, 0, 0, 0, 0};
@@ -504,12 +507,12 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       Item<T> mn, tn, vn;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
-        if (PARTS) g[it].x[l] = PC.template apply<false>(g[it].x[l], th[it].x[l], calc_logp, lp, dls_unused);
+        if (WITH_PRIOR) g[it].x[l] = PC.template apply<false>(g[it].x[l], th[it].x[l], calc_logp, lp, dls_unused);
         if (C.do_clamp) g[it].x[l] = clamp_grad<T>(g[it].x[l], C.clampv);
         update_elem<T, KIND>(C, (T)z[l], g[it].x[l], m[it].x[l], th[it].x[l], v[it].x[l], mn.x[l],
                              tn.x[l], vn.x[l], acc);
       }
-      if (PARTS) store_item<T>(gp + j, g[it]);  // p.grad holds the full gradient afterwards
+      if (WITH_PRIOR) store_item<T>(gp + j, g[it]);  // p.grad holds the full gradient afterwards
       if (save) {
         store_item<T>(pth + j, th[it]);
         store_item<T>(pg + j, g[it]);
@@ -537,13 +540,13 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
         if (l < n) {
-          if (PARTS) g.x[l] = PC.template apply<false>(g.x[l], th.x[l], calc_logp, lp, dls_unused);
+          if (WITH_PRIOR) g.x[l] = PC.template apply<false>(g.x[l], th.x[l], calc_logp, lp, dls_unused);
           if (C.do_clamp) g.x[l] = clamp_grad<T>(g.x[l], C.clampv);
           update_elem<T, KIND>(C, (T)z[l], g.x[l], m.x[l], th.x[l], v.x[l], mn.x[l], tn.x[l],
                                vn.x[l], acc);
         }
       }
-      if (PARTS) store_guarded<T>(gp + j, g, n);
+      if (WITH_PRIOR) store_guarded<T>(gp + j, g, n);
       if (save) {
         store_guarded<T>(pth + j, th, n);
         store_guarded<T>(pg + j, g, n);
@@ -556,10 +559,10 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       }
     }
   }
-  if (PARTS) {
+  if (WITH_PRIOR) {
     double a7[SGMCMC_NSUMS + 1] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], lp};
     block_reduce_store<SGMCMC_NSUMS + 1>(a7, L.partials + chunk * SGMCMC_PSTRIDE);
-    publish_batch_stats(L, G);
+    if (PARTS) publish_batch_stats(L, G);
   } else {
     block_reduce_store<SGMCMC_NSUMS>(acc, L.partials + chunk * SGMCMC_PSTRIDE);
   }
@@ -584,6 +587,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel_indirect(sgmcmc_layout L
   const sgmcmc_step_args A = *Ap;
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
   step_body<T, KIND, VEC, ITEMS, false>(L, A, none);
+}
+// ... with the closed-form prior gradient added in flight (SGMCMC_INLINE_PRIOR; float, lean priors)
+template <int KIND, bool VEC, int ITEMS>
+__global__ __launch_bounds__(kThreads) void step_kernel_indirect_prior(sgmcmc_layout L,
+                                                                       const sgmcmc_step_args* Ap) {
+  const sgmcmc_step_args A = *Ap;
+  const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
+  step_body<float, KIND, VEC, ITEMS, false, false, true>(L, A, none);
 }
 // ... and the gradient assembled in flight from per-slice partials + closed-form prior
 template <typename T, int KIND, bool VEC, int ITEMS>
@@ -1060,6 +1071,7 @@ void launch_step_mode(const sgmcmc_layout& L, const sgmcmc_step_args& A, const s
   const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
   if (G && Ad) SGMCMC_LAUNCH((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
   else if (G) SGMCMC_LAUNCH((step_kernel_parts_val<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A, *G);
+  else if (Ad && (A.flags & SGMCMC_INLINE_PRIOR)) SGMCMC_LAUNCH((step_kernel_indirect_prior<KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
   else if (Ad) SGMCMC_LAUNCH((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
   else if (VEC && ITEMS == 4 &&
            (double)L.n_chunks * (double)L.chunk_elems * sizeof(T) * 7.0 > 224.0 * 1024 * 1024)
@@ -1084,6 +1096,8 @@ int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_
     return (int)hipErrorInvalidValue;
   if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
   if (L->chunk_elems != SGMCMC_CHUNK && L->chunk_elems != SGMCMC_CHUNK_SMALL) return (int)hipErrorInvalidValue;
+  // the in-flight prior exists for the graph-replay kernel on float32 arenas only
+  if ((A->flags & SGMCMC_INLINE_PRIOR) && (!Ad || G || L->dtype != SGMCMC_F32)) return (int)hipErrorInvalidValue;
   const bool vec = !(A->flags & SGMCMC_UNALIGNED);
   const bool small = L->chunk_elems == SGMCMC_CHUNK_SMALL;
   if (L->dtype == SGMCMC_F32) {

@@ -112,6 +112,11 @@ class GraphedLeapfrog(_ReportSlots):
         self._slots = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(ring)]
         self._slot_events = [None] * ring
         self._k = 0
+        # closed-form priors without linked scales: the update kernel adds their gradient in flight (and leaves the
+        # log-density partials on metric steps) -- no prior launch in the captured step
+        eng = self.eng
+        self.inline_prior = (eng.small_finalize and not eng.prior_links and eng.prior_max_kind <= _hip.PRIOR_CAUCHY
+                             and eng.layout.dtype == _hip.F32)
         self._capture(x_example, y_example, warmup)
 
     # ------------------------------------------------------------------ args ring
@@ -130,6 +135,8 @@ class GraphedLeapfrog(_ReportSlots):
 
     def _args(self, calc_metrics=False):
         kind, flags, sc = self.opt._plain_step_spec(calc_metrics)
+        if self.inline_prior:
+            flags |= _hip.INLINE_PRIOR | (_hip.WITH_LOG_PRIOR if calc_metrics else 0)
         return self.eng.make_args(0, kind, flags, self.eng.next_draw(),
                                   grad_clamp=self.opt.grad_clamp, **sc)
 
@@ -140,13 +147,13 @@ class GraphedLeapfrog(_ReportSlots):
         self.opt.zero_grad()
         with _conv.deferring():
             f = self.pot._logits(self.x)
-            loss = _pool.cross_entropy(f, self.y)
-            loss.backward()
+            loss = _pool.cross_entropy_backward(f, self.y)
         with torch.no_grad():
             self.opt._prepare_hyper_grads()
         self.eng.refresh(self.opt._preconditioners(), defer_upload=capturing)
-        self.eng.prior_grad(self.pot.N, metrics)
-        self.eng.step_indirect(self._A_host, self.args_dev.data_ptr())
+        if not self.inline_prior:
+            self.eng.prior_grad(self.pot.N, metrics)
+        self.eng.step_indirect(self._A_host[metrics], self.args_dev.data_ptr())
         if not metrics:
             return loss.detach(), None
         with torch.no_grad():
@@ -178,8 +185,9 @@ class GraphedLeapfrog(_ReportSlots):
         self.x.copy_(x)
         self.y.copy_(y)
         snap = self._snapshot()
-        self._A_host = self._args()
-        self._push_args(self._A_host)
+        # (the host copies select kernels: INLINE_PRIOR / WITH_LOG_PRIOR differ between the two variants)
+        self._A_host = {m: self._args(calc_metrics=m) for m in (False, True)}
+        self._push_args(self._A_host[False])
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -295,8 +303,7 @@ class GraphedAccumulate:
         for p in params:
             p.grad = None
         with _conv.deferring():
-            this = _pool.cross_entropy(self.pot._logits(x), y, reduction="sum") / self.pot.N
-            this.backward()
+            this = _pool.cross_entropy_backward(self.pot._logits(x), y, reduction="sum", divide_by=self.pot.N)
         got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none
         torch._foreach_add_([a for a, _ in got], [g for _, g in got])
         self.loss += this.detach().double()

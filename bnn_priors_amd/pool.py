@@ -232,6 +232,36 @@ class _SoftmaxXent(torch.autograd.Function):
         return d, None, None
 
 
+def cross_entropy_backward(logits, y, reduction="mean", divide_by=None):
+    """``loss = F.cross_entropy(logits, y, reduction=...) [/ divide_by]; loss.backward()`` with the likelihood's
+    forward and backward in ONE launch: the kernel leaves the loss and d loss / d logits, and autograd is seeded
+    with the latter (``logits.backward(dlogits)``).  Same bits as ``cross_entropy(...)`` followed by
+    ``backward()``.  Returns the detached loss."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("reduction must be 'mean' or 'sum'")
+    if not (xent_supported(logits, y) and logits.requires_grad):
+        loss = cross_entropy(logits, y, reduction)
+        if divide_by is not None:
+            loss = loss / divide_by
+        loss.backward()
+        return loss.detach()
+    src, yc = logits.detach().contiguous(), y.contiguous()
+    b, k = src.shape
+    scale = 1.0 / b if reduction == "mean" else 1.0
+    import numpy as np
+    # the gradient autograd would hand the kernel: ones for the loss itself, (1 / divide_by) in float32 after a division
+    seed = np.float32(1.0) if divide_by is None else np.float32(1.0) / np.float32(divide_by)
+    gscale = float(seed * np.float32(scale))
+    d = torch.empty_like(src)
+    loss = torch.empty((), dtype=torch.float32, device=src.device)
+    err = _hip.lib().sgmcmc_softmax_xent_fwd_grad(src.data_ptr(), yc.data_ptr(), loss.data_ptr(), d.data_ptr(), b, k,
+                                                  float(scale), gscale, _conv._stream())
+    if err:
+        _hip.check(err, "sgmcmc_softmax_xent_fwd_grad")
+    logits.backward(d)
+    return loss if divide_by is None else loss / divide_by
+
+
 def cross_entropy(logits, y, reduction="mean"):
     """``F.cross_entropy(logits, y, reduction=...)`` ("mean" or "sum") -- one launch each way for float32
     logits of up to 1024 rows x 16 classes on the GPU, ATen otherwise"""

@@ -57,9 +57,12 @@ class Potential:
             return loss, log_prior, potential, accs.mean()
         with _conv.deferring():      # this pass's convolution weight-gradient slabs: one reduction at its end
             f = self._logits(x)
-            loss = _pool.cross_entropy(f, y)
             extra = self._leftover_log_prior()
-            (loss if extra is None else loss - extra / self.N).backward()
+            if extra is None:
+                loss = _pool.cross_entropy_backward(f, y)       # likelihood forward + backward seed: one launch
+            else:
+                loss = _pool.cross_entropy(f, y)
+                (loss - extra / self.N).backward()
         self.opt.add_prior_gradient(calc_log_prior=want_metrics)
         if not want_metrics:
             return loss.detach(), None, None, None
@@ -105,9 +108,8 @@ class Potential:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:
                 # (gradients accumulate into existing .grad tensors here, so nothing is deferred)
-                this = _pool.cross_entropy(self._logits(x), y, reduction="sum") / self.N
-                this.backward()
-                loss = loss + this.detach().double()
+                this = _pool.cross_entropy_backward(self._logits(x), y, reduction="sum", divide_by=self.N)
+                loss = loss + this.double()
         if acc is not None:
             acc.finish()
             loss = acc.loss.clone()

@@ -57,9 +57,14 @@ enum {
   SGMCMC_DEFER_FINALIZE = 256, /* launch only the update kernel; the per-segment bookkeeping is run
                                   later by sgmcmc_finalize or inside the next sgmcmc_dense_step_direct
                                   (it is not an input of the next gradient evaluation) */
-  SGMCMC_WITH_LOG_PRIOR = 128 /* with SMALL_FINALIZE + CALC_METRICS: partials[.][6] holds the
+  SGMCMC_WITH_LOG_PRIOR = 128, /* with SMALL_FINALIZE + CALC_METRICS: partials[.][6] holds the
                                  fused priors' log-density partials (sgmcmc_grad_reduce_prior):
                                  finish state[s].aux and scalars[2] in the same launch */
+  SGMCMC_INLINE_PRIOR = 512 /* sgmcmc_step_indirect only (float32 arena; priors of kind <= CAUCHY without linked
+                               scales): g holds the likelihood gradient alone and the update kernel adds the
+                               closed-form prior gradient in flight (and, on a CALC_METRICS step, leaves the
+                               log-density partials for WITH_LOG_PRIOR) -- no sgmcmc_prior_grad launch before it.
+                               g holds the full gradient afterwards, as after sgmcmc_prior_grad. */
 };
 /* element-wise priors the kernels differentiate in closed form (prior/loc_scale.py, prior/distributions.py:75-79)
  * and the element-wise hyper-priors of a hierarchical scale (prior/transformed.py:55-87, hierarchical.py:17-104):
@@ -547,6 +552,11 @@ int sgmcmc_softmax_xent_fwd(const float* logits, const int64_t* y, float* probs,
                             int classes, double scale, void* stream);
 int sgmcmc_softmax_xent_bwd(const float* probs, const int64_t* y, const float* grad_out, float* dlogits,
                             int rows, int classes, double scale, void* stream);
+/* The same loss AND its gradient in one launch, for a caller that seeds autograd itself (logits.backward(dlogits)):
+ * dlogits[b,k] = grad_scale * (softmax(logits_b)[k] - [k == y_b]) -- bit-identical to sgmcmc_softmax_xent_bwd on the
+ * saved probabilities with grad_out[0] * scale == grad_scale. */
+int sgmcmc_softmax_xent_fwd_grad(const float* logits, const int64_t* y, float* loss, float* dlogits, int rows,
+                                 int classes, double scale, float grad_scale, void* stream);
 
 /* Test hook: out[i] = spec normal (fp32) of noise index start+i. */
 int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, uint32_t stream,

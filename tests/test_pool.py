@@ -136,6 +136,33 @@ def test_softmax_cross_entropy_matches_aten(b, k, reduction):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,k", [(128, 10), (77, 3), (1024, 16)])
+@pytest.mark.parametrize("reduction,divide_by", [("mean", None), ("sum", 50000), ("sum", None)])
+def test_cross_entropy_backward_in_one_launch_has_the_bits_of_loss_backward(b, k, reduction, divide_by):
+    """pool.cross_entropy_backward (forward + autograd seed in one launch, what the captured step and the exact pass
+    use) == cross_entropy(...)[/ divide_by] followed by .backward(), bit for bit, through a layer upstream."""
+    g = torch.Generator().manual_seed(7 * b + k)
+    x = torch.randn(b, 12, generator=g).cuda()
+    w = (torch.randn(k, 12, generator=g) * .5).cuda()
+    y = torch.randint(0, k, (b,), generator=g).cuda()
+    w1 = w.clone().requires_grad_()
+    loss1 = pool.cross_entropy(x @ w1.t(), y, reduction)
+    if divide_by is not None:
+        loss1 = loss1 / divide_by
+    loss1.backward()
+    w2 = w.clone().requires_grad_()
+    loss2 = pool.cross_entropy_backward(x @ w2.t(), y, reduction, divide_by=divide_by)
+    assert not loss2.requires_grad
+    assert torch.equal(loss1.detach(), loss2)
+    assert torch.equal(w1.grad, w2.grad)
+    # unsupported inputs take the plain route
+    w3 = w.double().clone().requires_grad_()
+    loss3 = pool.cross_entropy_backward(x.double() @ w3.t(), y, reduction, divide_by=divide_by)
+    torch.testing.assert_close(loss3.float(), loss2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(w3.grad.float(), w2.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,j,k,with_bias", [(128, 2450, 10, True), (5, 2450, 10, False), (1, 7, 1, True), (128, 50, 16, True)])
 def test_narrow_linear_matches_float64(n, j, k, with_bias):
     "the convolutional classifier's head Linear(2450, 10) (models/conv_nets.py:57-70) and other narrow shapes"
