@@ -769,9 +769,12 @@ __device__ __forceinline__ void finalize_small_body(const sgmcmc_layout& L, cons
 // the spare slot partials[first_chunk][7], drains them (s_waitcnt vmcnt(0)), the workgroup takes a ticket with
 // a device-scope atomic; the workgroup that draws the last ticket reads the terms back with agent-scope loads
 // (MI355X_MICROARCH.md "Valid forms": 8-byte agent atomics on both sides) and resets the ticket.
-__device__ __forceinline__ void finalize_multi_body(const sgmcmc_layout& L, const sgmcmc_step_args& A) {
+// (bid, n_blocks): this workgroup's index among the workgroups doing the bookkeeping -- the whole grid for the
+// kernels below, the tail of a staging launch for a deferred one (augment_hip.inc)
+__device__ __forceinline__ void finalize_multi_body(const sgmcmc_layout& L, const sgmcmc_step_args& A, int bid,
+                                                    int n_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = (int)blockDim.x >> 6;
-  const int gw = (int)blockIdx.x * wpb + wave, n_w = (int)gridDim.x * wpb;
+  const int gw = bid * wpb + wave, n_w = n_blocks * wpb;
   for (int seg = A.seg_begin + gw; seg < A.seg_end; seg += n_w) {
     const sgmcmc_segment s = L.segs[seg];
     double pre[3] = {0.0, 0.0, 0.0};
@@ -805,7 +808,7 @@ __device__ __forceinline__ void finalize_multi_body(const sgmcmc_layout& L, cons
   unsigned long long* ticket = reinterpret_cast<unsigned long long*>(L.scalars + 7);
   if (threadIdx.x == 0) {
     const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t + 1 == (unsigned long long)gridDim.x);
+    is_last = (t + 1 == (unsigned long long)n_blocks);
   }
   __syncthreads();
   if (!is_last) return;
@@ -833,12 +836,12 @@ __global__ __launch_bounds__(kThreads) void finalize_step_kernel(sgmcmc_layout L
   finalize_step_body(L, A);
 }
 __global__ __launch_bounds__(kThreads) void finalize_multi_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
-  finalize_multi_body(L, A);
+  finalize_multi_body(L, A, (int)blockIdx.x, (int)gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void finalize_multi_kernel_indirect(sgmcmc_layout L,
                                                                            const sgmcmc_step_args* Ap) {
   const sgmcmc_step_args A = *Ap;
-  finalize_multi_body(L, A);
+  finalize_multi_body(L, A, (int)blockIdx.x, (int)gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void finalize_step_kernel_indirect(sgmcmc_layout L,
                                                                           const sgmcmc_step_args* Ap) {
@@ -1110,6 +1113,13 @@ int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_
     return (int)hipErrorInvalidValue;
   }
   return 0;
+}
+
+// how the bookkeeping of a SMALL_FINALIZE transition is spread: several workgroups (a wave per segment) for many
+// tensors and no log-prior to finish, else one
+inline int finalize_blocks(const sgmcmc_step_args& A) {
+  const int n_segs = A.seg_end - A.seg_begin;
+  return (n_segs > 8 && !(A.flags & SGMCMC_WITH_LOG_PRIOR)) ? (n_segs + 3) / 4 : 1;
 }
 
 void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_step_args* Ad,

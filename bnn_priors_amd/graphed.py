@@ -37,10 +37,11 @@ def _stageable(dst, src):
             and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0 and (dst.numel() * dst.element_size()) % 4 == 0)
 
 
-def stage_batch(x_dst, x, y_dst, y, args_dst=None, args_pinned=None):
+def stage_batch(x_dst, x, y_dst, y, args_dst=None, args_pinned=None, engine=None):
     """x_dst <- x, y_dst <- y (and the argument block from its pinned slot) in one launch when the batch is a
     contiguous device tensor of the static inputs' dtype; anything else (a host batch, a strided view, another
-    dtype) goes through ``Tensor.copy_``, which converts."""
+    dtype) goes through ``Tensor.copy_``, which converts.  With ``engine``: a transition whose bookkeeping is
+    still pending (``engine.pending``) has it executed by the same launch."""
     jobs = []
     for dst, src in ((x_dst, x), (y_dst, y)):
         if src is None:
@@ -55,11 +56,19 @@ def stage_batch(x_dst, x, y_dst, y, args_dst=None, args_pinned=None):
         else:
             args_dst.copy_(args_pinned, non_blocking=True)
     if not jobs:
+        if engine is not None:
+            engine.flush()
         return
+    pending = None
+    if engine is not None:
+        pending, engine.pending = engine.pending, None
     n = len(jobs)
     src, dst, nb = (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]), \
         (ctypes.c_int64 * n)(*[j[2] for j in jobs])
-    _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n, torch.cuda.current_stream(x_dst.device).cuda_stream),
+    _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n,
+                                             ctypes.byref(engine.layout) if pending is not None else None,
+                                             ctypes.byref(pending) if pending is not None else None,
+                                             torch.cuda.current_stream(x_dst.device).cuda_stream),
                "sgmcmc_stage_batch")
 
 
@@ -117,6 +126,7 @@ class GraphedLeapfrog(_ReportSlots):
         eng = self.eng
         self.inline_prior = (eng.small_finalize and not eng.prior_links and eng.prior_max_kind <= _hip.PRIOR_CAUCHY
                              and eng.layout.dtype == _hip.F32)
+        self.defer_finalize = bool(eng.small_finalize)
         self._capture(x_example, y_example, warmup)
 
     # ------------------------------------------------------------------ args ring
@@ -129,14 +139,18 @@ class GraphedLeapfrog(_ReportSlots):
         if ev is not None:
             ev.synchronize()            # the copy that last used this slot has executed
         ctypes.memmove(self._slots[i].data_ptr(), ctypes.addressof(A), ctypes.sizeof(A))
-        stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i])
+        stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i], self.eng)
         ev = self._slot_events[i] = ev or torch.cuda.Event()
         ev.record()
 
-    def _args(self, calc_metrics=False):
+    def _args(self, calc_metrics=False, variant=None):
+        "``variant``: which captured graph runs the step (default: the one named by ``calc_metrics``)"
+        variant = calc_metrics if variant is None else variant
         kind, flags, sc = self.opt._plain_step_spec(calc_metrics)
         if self.inline_prior:
             flags |= _hip.INLINE_PRIOR | (_hip.WITH_LOG_PRIOR if calc_metrics else 0)
+        if self.defer_finalize and not variant:      # (the metric variant finalizes inside its graph)
+            flags |= _hip.DEFER_FINALIZE    # the bookkeeping rides in the next step's staging launch
         return self.eng.make_args(0, kind, flags, self.eng.next_draw(),
                                   grad_clamp=self.opt.grad_clamp, **sc)
 
@@ -229,8 +243,11 @@ class GraphedLeapfrog(_ReportSlots):
         eng.refresh(self.opt._preconditioners())
         # ``metrics`` picks the graph variant (with accuracy / log-prior / packed read-back);
         # ``calc_metrics`` (default: the same) is the sampler's own flag, read from the args at run time
-        self._push_args(self._args(calc_metrics=metrics if calc_metrics is None else calc_metrics), x, y)
+        A = self._args(calc_metrics=metrics if calc_metrics is None else calc_metrics, variant=metrics)
+        self._push_args(A, x, y)
         self.graphs[metrics].replay()
+        if A.flags & _hip.DEFER_FINALIZE:
+            eng.pending = A
         eng._touch()
         eng.energy_ready = True
         if not metrics:

@@ -216,6 +216,8 @@ class Engine:
             if M[i] != m:
                 M[i] = m
                 self._seg_dirty = True
+                # a transition's pending bookkeeping reads ITS preconditioner from the segment table
+                self.flush()
         self._precond_dirty = False
         if self._seg_dirty and not defer_upload:   # deferred: during hipGraph capture
             self._upload_segments()
@@ -255,9 +257,11 @@ class Engine:
     prior_max_kind = 0
 
     # ------------------------------------------------------------------ deferred finalize
-    # The fused dense step leaves a transition's per-segment bookkeeping pending (it is not an
-    # input of the next gradient evaluation) and runs it inside its NEXT launch; anything else
-    # that touches the partials / state calls flush() first.
+    # The fused dense step and the captured step leave a transition's per-segment bookkeeping pending (it is
+    # not an input of the next gradient evaluation) and run it inside their NEXT launch (the gradient kernel /
+    # the batch staging kernel); anything else that touches the partials / state calls flush() first.
+    # (The bookkeeping reads a segment's M, numel and whether it HAS a gradient from the segment table, never
+    # the pointers: re-binding p.grad to another graph's static tensors does not disturb it.)
     pending = None
 
     def flush(self):

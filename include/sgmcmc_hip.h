@@ -541,8 +541,12 @@ int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, con
  * captured step -- the minibatch (x, y) into the graph's static inputs and the argument block from PINNED host
  * memory (the kernel reads it over the bus) -- which otherwise costs three copy dispatches between two graph
  * launches.  Pointers 16-byte aligned, sizes multiples of 4; else hipErrorInvalidValue.  No reference counterpart:
- * the reference's batches arrive from its DataLoader (experiments/train_bnn.py:172-180). */
-int sgmcmc_stage_batch(const void* const* src, void* const* dst, const int64_t* bytes, int n_copies, void* stream);
+ * the reference's batches arrive from its DataLoader (experiments/train_bnn.py:172-180).
+ * A_pending (may be NULL; else with L): the previous transition was launched with SGMCMC_DEFER_FINALIZE
+ * (SMALL_FINALIZE layouts) and its per-segment bookkeeping is executed by extra workgroups of THIS launch -- the
+ * same results as sgmcmc_finalize(L, A_pending) at this point of the stream. */
+int sgmcmc_stage_batch(const void* const* src, void* const* dst, const int64_t* bytes, int n_copies,
+                       const sgmcmc_layout* L, const sgmcmc_step_args* A_pending, void* stream);
 
 /* loss = scale * sum_b -log softmax(logits_b)[y_b] for up to 1024 rows of up to 16 classes (the likelihood term of
  * models/base.py:168-191), one launch each way: forward keeps probs [rows][classes] for the backward,

@@ -172,7 +172,7 @@ def test_stage_batch_copies_up_to_three_buffers_in_one_launch_bit_exactly():
         src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
         dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
         nb = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in srcs])
-        _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n, torch.cuda.current_stream(dev).cuda_stream), "stage")
+        _hip.check(_hip.lib().sgmcmc_stage_batch(src, dst, nb, n, None, None, torch.cuda.current_stream(dev).cuda_stream), "stage")
         torch.cuda.synchronize(dev)
         for s, d in zip(srcs, dsts):
             assert torch.equal(s.to(dev), d)
@@ -180,7 +180,7 @@ def test_stage_batch_copies_up_to_three_buffers_in_one_launch_bit_exactly():
     src = (ctypes.c_void_p * 1)(x.data_ptr() + 4)
     dst = (ctypes.c_void_p * 1)(xd.data_ptr())
     nb = (ctypes.c_int64 * 1)(64)
-    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, 0) != 0
+    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, None, None, 0) != 0
     src = (ctypes.c_void_p * 1)(x.data_ptr())
     nb = (ctypes.c_int64 * 1)(63)
-    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, 0) != 0
+    assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, None, None, 0) != 0
