@@ -206,6 +206,8 @@ EXPORTS = {
                               + [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
     "sgmcmc_softmax_xent_fwd_grad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                     ctypes.c_float, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd_add": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 3
+                               + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
     "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3

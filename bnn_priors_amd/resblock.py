@@ -92,26 +92,29 @@ def _reduce_or_defer(lib, w, part, n_slabs, s):
     return dw
 
 
-def _conv_bn_bwd_two_launch(lib, x, w, y, out, dout, saved, g, dgb, want_dz, s):
+def _conv_bn_bwd_two_launch(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
     """the same gradients with the BatchNorm backward as its own two launches (sums, dx) before conv3x3_bwd;
-    ``want_dz``: also return dz = dout * [out > 0] (what the shortcut carries)"""
+    e_dout / e_out: dx += e_dout * [e_out > 0] in the data gradient's epilogue (what the shortcut carries)"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=x.device)
     dy = torch.empty_like(x)
-    dz = torch.empty_like(x) if want_dz else None
     err = lib.sgmcmc_bn_train_bwd(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
-                                  saved[1].data_ptr(), 1, n, c, hw * hw, dy.data_ptr(), _p(dz), dgb[0].data_ptr(),
+                                  saved[1].data_ptr(), 1, n, c, hw * hw, dy.data_ptr(), 0, dgb[0].data_ptr(),
                                   dgb[1].data_ptr(), scratch.data_ptr(), s)
     if err:
         _hip.check(err, "sgmcmc_bn_train_bwd")
     part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     slabs = ctypes.c_int(0)
-    err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), n, c, hw,
-                                 ctypes.byref(slabs), s)
+    if e_dout is None:
+        err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), n, c, hw,
+                                     ctypes.byref(slabs), s)
+    else:
+        err = lib.sgmcmc_conv3x3_bwd_add(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), e_dout.data_ptr(),
+                                         e_out.data_ptr(), 0, part.data_ptr(), n, c, hw, ctypes.byref(slabs), s)
     if err:
         _hip.check(err, "sgmcmc_conv3x3_bwd")
-    return dx, _reduce_or_defer(lib, w, part, slabs.value, s), dz
+    return dx, _reduce_or_defer(lib, w, part, slabs.value, s)
 
 
 def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
@@ -163,9 +166,8 @@ class _Block(torch.autograd.Function):
             # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue
             dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
         else:
-            dh, dw2, dz2 = _conv_bn_bwd_two_launch(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], True, s)
-            dx, dw1, _ = _conv_bn_bwd_two_launch(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], False, s)
-            dx.add_(dz2)
+            dh, dw2 = _conv_bn_bwd_two_launch(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
+            dx, dw1 = _conv_bn_bwd_two_launch(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
         return (dx, dw1, dgb[0, 0], dgb[0, 1], dw2, dgb[1, 0], dgb[1, 1]) + (None,) * 8
 
 

@@ -394,6 +394,12 @@ typedef struct sgmcmc_reduce_job {
 } sgmcmc_reduce_job;
 int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
                        float* scratch, int n_img, int channels, int hw, int* deferred_slabs, void* stream);
+/* ... with dx += e_dout * [e_out > 0] in the data gradient's epilogue: the gradient a residual block's identity
+ * shortcut carries back to the block input (models/google_resnet.py:52-56: out = relu(bn2(conv2(h)) + x)), added where
+ * the first convolution's data gradient is produced instead of by a separate element-wise pass. */
+int sgmcmc_conv3x3_bwd_add(const float* x, const float* w, const float* dy, float* dx, const float* e_dout,
+                           const float* e_out, float* dw, float* scratch, int n_img, int channels, int hw,
+                           int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;

@@ -110,6 +110,37 @@ def test_gradients_are_reproducible_and_inputs_untouched():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c,hw", SHAPES)
+@pytest.mark.parametrize("n", [128, 3])
+def test_backward_with_the_shortcut_gradient_added_in_its_epilogue(c, hw, n):
+    """sgmcmc_conv3x3_bwd_add: dx = data gradient + e_dout * [e_out > 0], same bits as the plain backward followed
+    by the element-wise add; the weight gradient is untouched by the epilogue."""
+    import ctypes
+    lib = _hip.lib()
+    x, w, dy = (t.cuda() for t in _data(c, hw, n, seed=5))
+    g = torch.Generator().manual_seed(c + n)
+    e_dout = torch.randn(n, c, hw, hw, generator=g).cuda()
+    e_out = torch.relu(torch.randn(n, c, hw, hw, generator=g)).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for add in (False, True):
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), device="cuda")
+        if add:
+            err = lib.sgmcmc_conv3x3_bwd_add(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), e_dout.data_ptr(),
+                                             e_out.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n, c, hw, None, s)
+        else:
+            err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                         scratch.data_ptr(), n, c, hw, None, s)
+        _hip.check(err, "bwd")
+        outs.append((dx, dw))
+    assert torch.equal(outs[1][0], outs[0][0] + e_dout * (e_out > 0))
+    assert torch.equal(outs[1][1], outs[0][1])
+    assert lib.sgmcmc_conv3x3_bwd_add(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, e_out.data_ptr(),
+                                      dw.data_ptr(), scratch.data_ptr(), n, c, hw, None, s) != 0
+
+
+@pytest.mark.gpu
 def test_abi_rejects_shapes_outside_the_table():
     lib = _hip.lib()
     x = torch.zeros(2, 48, 16, 16, device="cuda")
