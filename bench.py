@@ -80,6 +80,12 @@ def parse():
     ap.add_argument("--trajectory", type=int, default=0,
                     help="HMCReject only: leapfrog steps per trajectory (BASELINE configs[4]: 50); 0 = one epoch")
     ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--weight-prior", default=None,
+                    help="weight prior family (default: the workload's BASELINE config; HMCReject with --trajectory: "
+                         "student-t, configs[4])")
+    ap.add_argument("--augment", type=int, default=1,
+                    help="googleresnet: every minibatch is gathered from the HBM-resident set through the on-device "
+                         "random crop (pad 4) + flip, as configs[3]'s cifar10_augmented (data/CIFAR/cifar.py:136-172)")
     ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
     ap.add_argument("--chain-sweep", default="1,2,4,8",
                     help="densenet only: aggregate steps/s of K chains sharing ONE GPU's launches (MultiChainDense); '' = skip")
@@ -117,9 +123,10 @@ class PoolSource:
             yield IndexBatch(idx, self.x, self.y), None
 
 
-def make_model(workload, device):
+def make_model(workload, device, prior=None):
     from bnn_priors_amd import models
-    name, xshape, _, prior = WORKLOADS[workload]
+    name, xshape, _, default_prior = WORKLOADS[workload]
+    prior = prior or default_prior
     torch.manual_seed(0)
     x0 = torch.zeros((2,) + xshape)
     net = models.get_model(x0, torch.tensor([0, 9]), name, width=50, depth=3, weight_prior=prior,
@@ -169,10 +176,12 @@ class PacketTimer:
 
 def conv_rooflines(device, n_img=128, iters=60):
     """The ResNet trunk's convolution kernels against the fp32-MFMA peak: each of the three trunk shapes,
-    forward (``conv3x3_kernel`` + batch statistics) and both gradients (``conv3x3_bwd_kernel``), launched
-    through the C ABI on synthetic tensors with the same shapes as in the step.  Algorithmic flops:
-    2 * N * HW^2 * C^2 * 9 per convolution-shaped contraction (forward: one; backward: two)."""
-    from bnn_priors_amd import _hip
+    forward (``conv3x3_kernel`` + batch statistics) and both gradients -- ``conv3x3_bwd_kernel``, and
+    ``fused_bwd_kernel`` (BatchNorm backward formed while staging) for the shapes whose blocks take that route
+    (resblock.FUSED_BN_BWD) -- launched through the C ABI on synthetic tensors with the same shapes as in the step.
+    Algorithmic flops: 2 * N * HW^2 * C^2 * 9 per convolution-shaped contraction (forward: one; backward: two).
+    ``launches_per_step``: how often googleresnet's step runs the kernel (6 + 5 + 5 trunk convolutions)."""
+    from bnn_priors_amd import _hip, resblock
     lib = _hip.lib()
     stream = torch.cuda.current_stream(device).cuda_stream
     rows = []
@@ -186,6 +195,20 @@ def conv_rooflines(device, n_img=128, iters=60):
         scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n_img, c, hw), device=device)
         slabs = ctypes.c_int(0)
         flop1 = 2.0 * n_img * hw * hw * c * c * 9
+        out = torch.relu(torch.randn((n_img, c, hw, hw), generator=g, device=device))
+        sums = torch.zeros(lib.sgmcmc_bn_scratch_doubles(n_img, c, hw * hw), dtype=torch.float64, device=device)
+        saved = torch.stack([torch.zeros(c, device=device), torch.ones(c, device=device)])
+        gamma, dgb = torch.ones(c, device=device), torch.empty((2, c), device=device)
+        n_sums = ctypes.c_int(0)
+        _hip.check(lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
+                                          saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n_img, c,
+                                          hw * hw, stream), "sgmcmc_bn_bwd_sums")
+        A = _hip.ConvBnBwdArgs(dout=dy.data_ptr(), mask_out=out.data_ptr(), y=y.data_ptr(), mean=saved[0].data_ptr(),
+                               invstd=saved[1].data_ptr(), gamma=gamma.data_ptr(), sums=sums.data_ptr(),
+                               n_sums=n_sums.value, reserved=0, dgamma=dgb[0].data_ptr(), dbeta=dgb[1].data_ptr(),
+                               e_dout=0, e_out=0)
+        fused_route = (c, hw) in resblock.FUSED_BN_BWD
+        n_convs = 6 if c == 16 else 5          # trunk convolutions of this shape in googleresnet (depth 20)
 
         def fwd():
             _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n_img, c, hw, 0,
@@ -195,8 +218,15 @@ def conv_rooflines(device, n_img=128, iters=60):
             _hip.check(lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(),
                                               dw.data_ptr(), scratch.data_ptr(), n_img, c, hw,
                                               ctypes.byref(slabs), stream), "sgmcmc_conv3x3_bwd")
-        for name, fn, flops in ((f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1),
-                                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1)):
+        def bn_bwd():
+            _hip.check(lib.sgmcmc_conv3x3_bn_bwd(x.data_ptr(), w.data_ptr(), dx.data_ptr(), scratch.data_ptr(),
+                                                 ctypes.byref(A), n_img, c, hw, ctypes.byref(slabs), stream),
+                       "sgmcmc_conv3x3_bn_bwd")
+        # (the down-sampling block's second convolution has no identity-shortcut block around it: plain route)
+        for name, fn, flops, per_step in (
+                (f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1, n_convs),
+                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1, n_convs if not fused_route else 1),
+                (f"conv::fused_bwd_kernel<{c},{hw},8>", bn_bwd, 2 * flop1, n_convs - 1 if fused_route else 0)):
             for _ in range(5):
                 fn()
             torch.cuda.synchronize(device)
@@ -210,7 +240,7 @@ def conv_rooflines(device, n_img=128, iters=60):
             rows.append(dict(kernel=name, bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS,
                              unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
                              algorithmic_flops_per_launch=flops, avg_kernel_us=round(avg * 1e3, 3),
-                             min_kernel_us=round(min(ms) * 1e3, 3), launches=len(ms),
+                             min_kernel_us=round(min(ms) * 1e3, 3), launches=len(ms), launches_per_step=per_step,
                              shape=dict(n=n_img, channels=c, hw=hw)))
     return rows
 
@@ -388,9 +418,11 @@ def main():
     hmc = args.inference == "HMCReject"
     if hmc and args.trajectory:
         N = 128 * args.trajectory          # BASELINE configs[4]: a synthetic set of L batches, epoch = trajectory = L steps
+        prior = "student-t"                # ... with its weight prior
+    prior = args.weight_prior or prior
     L = -(-N // 128)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
-    model = make_model(args.workload, device)
+    model = make_model(args.workload, device, prior)
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
     n_params = sum(p.numel() for p in model.parameters())
@@ -417,13 +449,21 @@ def main():
     fused = runner._fused_dense() is not None
     batches = list(pool.index_batches()) if fused else list(pool)
     batches = [b for b in batches if len(b[0]) == 128]       # the L-th minibatch is ragged (N % 128)
+    augment = None
+    if args.workload == "googleresnet" and args.augment and not fused:
+        from bnn_priors_amd.augment import RandomCropFlip
+        augment = RandomCropFlip(pad=4, flip=True, seed=1234, stream=rank)
+        rows = [torch.arange(128 * b, 128 * (b + 1), device=device) for b in range(len(batches))]
     path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
             "eager" if args.eager else "hipGraph of autograd fwd/bwd (hand-written conv / BN kernels) + fused sampler")
 
     def run(k, step):
         for _ in range(k):
             step += 1
-            x, y = batches[step % len(batches)]
+            b = step % len(batches)
+            x, y = batches[b]
+            if augment is not None:     # a fresh crop / flip of every image at every visit (draw = the pass counter)
+                x = augment.gather(pool.x, rows[b], step // len(batches))
             runner.leapfrog(step, x, y, last_of_epoch=False)
         return step
 
@@ -484,11 +524,14 @@ def main():
         # one stored sample = L leapfrog steps + the exact full-data gradient + final_step + M-H test
         # + initial_step (inference_reject.py:86-157); timed end to end, K times
         all_b = list(pool.index_batches()) if fused else list(pool)
+        rows_all = [torch.arange(128 * b, min(128 * (b + 1), N), device=device) for b in range(len(all_b))]
         opt = runner.optimizer
 
         def one_sample(step, reject=runner.reject_samples):
             for i, (x, y) in enumerate(all_b):
                 step += 1
+                if augment is not None:
+                    x = augment.gather(pool.x, rows_all[i], step // len(all_b))
                 runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
             step += 1
             loss, log_prior, potential = runner._exact_model_potential_and_grad(pool)
@@ -529,6 +572,7 @@ def main():
         "config": {"workload": f"{name} {args.inference} batch=128 N={N} (L={L} steps/epoch) "
                                f"lr={'1e-4' if hmc else '0.01'} cosine momentum={'1' if hmc else '0.994'} "
                                f"T={args.temperature:g} metrics_skip={args.metrics_skip} prior={prior}"
+                               + (" augment=crop(pad 4)+flip on device" if augment is not None else "")
                                + (f" trajectory={args.trajectory}" if hmc and args.trajectory else ""),
                    "params": n_params, "tensors": len(list(model.parameters())),
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
@@ -573,10 +617,9 @@ def main():
             # the step is dominated by the trunk's convolution gradients (profiles/): the headline roofline is
             # the kernel with the largest share of the step, the sampler's HBM line is reported beside it
             convs = conv_rooflines(device)
-            share = {r["kernel"]: r["avg_kernel_us"] * (6 if r["shape"]["channels"] == 16 else 5) for r in convs}
-            top = max(convs, key=lambda r: share[r["kernel"]])
+            top = max(convs, key=lambda r: r["avg_kernel_us"] * r["launches_per_step"])
             out["roofline"] = dict(top, share_note="dominant kernel = largest (launches per step x duration) among "
-                                                   "the step's kernels; 5-6 launches per step each")
+                                                   "the step's kernels")
             out["roofline_kernels"] = convs
             if sampler_line:
                 out["roofline_sampler"] = sampler_line
@@ -589,7 +632,7 @@ def main():
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]
-            res = time_cpu_baseline(lambda: make_model(args.workload, "cpu"), cpu_batches,
+            res = time_cpu_baseline(lambda: make_model(args.workload, "cpu", prior), cpu_batches,
                                     num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
                                     steps_per_cycle=L * 50, budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
