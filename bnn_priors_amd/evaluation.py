@@ -16,6 +16,8 @@ instead of gathering [E, N, C] from every GPU.
 import contextlib
 import math
 
+import os
+
 import torch
 
 __all__ = ("evaluate_model", "predictive_tables", "ensemble_across_chains", "ensemble_metrics",
@@ -35,7 +37,7 @@ def _n_samples(samples):
     return min(len(v) for v in samples.values())
 
 
-BATCHED = True          # stack the samples and run ONE grouped forward per test batch (classification models)
+BATCHED = os.environ.get("SGMCMC_EVAL_BATCHED", "1") != "0"   # stack the samples: ONE grouped forward per test batch
 SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation memory at E_group * batch images
 
 
