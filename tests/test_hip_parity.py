@@ -145,6 +145,51 @@ def test_step_bit_exact_vs_c_oracle(kind, a, T, dtype):
         _assert_state_bit_exact(params, opt, fa, what="after partial refresh")
 
 
+def _baseline_numels(workload):
+    "tensor sizes of BASELINE.json's nets (configs[1], [2], [3]), in parameter order"
+    from bnn_priors_amd import models
+    name, xshape = {"densenet": ("classificationdensenet", (784,)), "convnet": ("classificationconvnet", (784,)),
+                    "googleresnet": ("googleresnet", (3, 32, 32))}[workload]
+    net = models.get_model(torch.zeros((2,) + xshape), torch.tensor([0, 9]), name, width=50, depth=3,
+                           weight_prior="gaussian", weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
+    return [p.numel() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("kind,a,T", [("verlet", 0.994, 1.0), ("hmc", 1.0, 1.0)])
+@pytest.mark.parametrize("workload,total", [("densenet", 42310), ("convnet", None), ("googleresnet", 272474),
+                                            ("flat_2p24", (1 << 24) + 3)])
+def test_step_bit_exact_at_baseline_sizes(workload, total, kind, a, T):
+    """The sampler transition at BASELINE.json's FULL sizes -- the three nets' real tensor lists, and one 2^24 + 3
+    element segment (the non-temporal streaming variant of the kernel) -- against the C oracle, bit for bit:
+    momentum refresh, initial / ordinary / final step with saved state, the six fp64 sums to 1e-12."""
+    numels = [total] if workload.startswith("flat") else _baseline_numels(workload)
+    if total is not None:
+        assert sum(numels) == total
+    dtype = torch.float32
+    params, opt, fa, g = _setup(kind, dtype, a, T, numels=numels)
+    opt.sample_momentum()
+    fa.sample_momentum(math.sqrt(T if kind != "hmc" else 1.0), 0.0, 4242, 0, stream=2)
+    _assert_state_bit_exact(params, opt, fa, what="after sample_momentum")
+    calls = [("initial", FLAG_INITIAL | FLAG_SAVE), ("middle", 0), ("final", FLAG_FINAL)]
+    for step_i, (which, flags) in enumerate(calls):
+        _set_grads(params, fa, g, dtype)
+        if which == "initial":
+            opt.initial_step(save_state=True)
+        elif which == "middle":
+            opt.step()
+        else:
+            opt.final_step()
+        grp = opt.param_groups[0]
+        sums = fa.step(kind, grad_v=grp['grad_v'], bhn=grp['bhn'], bh=grp['bh'], mom_decay=grp['mom_decay'],
+                       noise_std=grp['noise_std'], alpha=0.99, seed=4242, draw=step_i + 1, stream=2, flags=flags).copy()
+        _assert_state_bit_exact(params, opt, fa, what=f"after {which} #{step_i}")
+        np.testing.assert_allclose(opt.engine.fetch_state()[:, :6], sums, rtol=1e-12, atol=1e-300)
+    for s_, p in enumerate(params):        # the saved M-H state of the initial step
+        assert np.array_equal(opt.state[p]['prev_parameter'].cpu().numpy(), fa.seg(fa.prev_theta, s_))
+        assert np.array_equal(opt.state[p]['prev_grad'].cpu().numpy(), fa.seg(fa.prev_g, s_))
+
+
+
 def test_unaligned_pointers_take_scalar_path_and_agree():
     "parameters that are views at odd offsets of a bigger buffer (4-byte aligned only)"
     mcmc = _mcmc()
