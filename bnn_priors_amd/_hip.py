@@ -77,6 +77,11 @@ class ReduceJob(ctypes.Structure):
                 ("numel", ctypes.c_int32), ("taps", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class ConvBwdEpilogue(ctypes.Structure):
+    "sgmcmc_conv_bwd_epilogue"
+    _fields_ = [(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
+
+
 class ConvBnBwdArgs(ctypes.Structure):
     "sgmcmc_conv_bn_bwd_args"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("dout", "mask_out", "y", "mean", "invstd", "gamma", "sums")]
@@ -208,6 +213,10 @@ EXPORTS = {
                                                     ctypes.c_float, ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd_add": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 3
                                + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
+                              + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_bn_bwd_dx": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+                         + [ctypes.c_void_p] * 5),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
     "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3

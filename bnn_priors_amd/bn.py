@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import _hip
+from . import bnlink as _bnlink
 
 ENABLED = os.environ.get("SGMCMC_BN", "1") != "0"
 
@@ -54,13 +55,19 @@ class _BNTrain(torch.autograd.Function):
             _hip.check(err, "sgmcmc_bn_train_fwd")
         ctx.save_for_backward(x, weight, y if relu else None, stats)
         ctx.relu, ctx.has_residual = bool(relu), residual is not None
-        return y
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return y, stats
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         lib = _hip.lib()
         x, weight, y, stats = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 10
+        # the launch that produced dy may have left this BatchNorm's channel sums with it (bnlink)
+        up = _bnlink.sums_of(dy) if ctx.relu else None
         dy = dy.contiguous()
         n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
         dx = torch.empty_like(x)
@@ -70,6 +77,14 @@ class _BNTrain(torch.autograd.Function):
         else:
             dres = torch.empty_like(x) if want_res else None
         dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        if up is not None:
+            err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(), stats[0].data_ptr(),
+                                       stats[1].data_ptr(), 1, n, c, plane, up[0].data_ptr(), up[1], dx.data_ptr(),
+                                       0 if dres is dy else _ptr(dres), dwb[0].data_ptr(), dwb[1].data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+            if err:
+                _hip.check(err, "sgmcmc_bn_bwd_dx")
+            return dx, dwb[0], dwb[1], dres, None, None, None, None, None, None
         scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
         err = lib.sgmcmc_bn_train_bwd(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(),
                                       stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu), n, c, plane,
@@ -85,4 +100,7 @@ def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual
     """``stats``: per-slice partial (sum, sum of squared deviations from the slice mean) of x over equal parts of (N, H, W) per channel, float64
     [channels][slices][2], if the producer of x already has them (``conv.conv3x3(..., want_stats=True)``);
     the statistics pass over x is skipped then."""
-    return _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)
+    out, saved = _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)
+    if relu:      # a convolution that consumes `out` can produce this BatchNorm's backward sums (bnlink)
+        _bnlink.tag_output(out, x, saved)
+    return out

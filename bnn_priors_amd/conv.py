@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import _hip
+from . import bnlink as _bnlink
 
 import contextlib
 
@@ -107,15 +108,27 @@ def _weight_grad(x, dy):
     return dw
 
 
-def _both_grads(x, w, dy, defer):
+def _both_grads(x, w, dy, defer, sums_for=None):
+    "``sums_for`` = (y_bn, out_bn, saved_bn) of the BatchNorm + ReLU that produced x: its backward sums ride along"
     lib = _hip.lib()
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
     slabs = ctypes.c_int(0)
-    err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                 scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None, _stream())
+    if sums_for is None:
+        err = lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                     scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None, _stream())
+    else:
+        y_bn, out_bn, saved_bn = sums_for
+        n_part = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
+        partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
+        E = _hip.ConvBwdEpilogue(s_y=y_bn.data_ptr(), s_out=out_bn.data_ptr(), s_mean=saved_bn[0].data_ptr(),
+                                 s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr())
+        err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
+                                        dw.data_ptr(), scratch.data_ptr(), n, c, hw,
+                                        ctypes.byref(slabs) if defer else None, _stream())
+        _bnlink.tag_gradient(dx, partial, n_part)
     if err:
         _hip.check(err, "sgmcmc_conv3x3_bwd")
     if defer:
@@ -145,10 +158,10 @@ def _flush_pending():
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, want_stats):
+    def forward(ctx, x, w, want_stats, src_y=None, src_saved=None):
         _note_use(w)
         x, w = x.contiguous(), w.contiguous()
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, src_y, src_saved)
         ctx.set_materialize_grads(False)     # no zero tensors for the (non-differentiable) statistics output
         y, stats = _run(x, w, False, want_stats)
         if not want_stats:
@@ -159,25 +172,27 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, *_):
-        x, w = ctx.saved_tensors
+        x, w, src_y, src_saved = ctx.saved_tensors
         if dy is None:                 # the output took no gradient (grads are not materialised here)
-            return None, None, None
+            return None, None, None, None, None
         dy = dy.contiguous()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             defer = _may_defer(w)
             if defer:   # every deferring call queues it; the first one to run does the work
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
-            return (*_both_grads(x, w, dy, defer), None)         # one launch for the two of them
+            # one launch for the two of them (+ the sums of the BatchNorm that produced x, if x is tagged)
+            return (*_both_grads(x, w, dy, defer, None if src_y is None else (src_y, x, src_saved)), None, None, None)
         dx = _run(dy, w, True)[0] if ctx.needs_input_grad[0] else None
         dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
-        return dx, dw, None
+        return dx, dw, None, None, None
 
 
 def conv3x3(x, w, want_stats=False):
     """3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES.
     ``want_stats``: also return the per-band (sum, sum of squared deviations from the band mean) of every output channel, float64
     [channels][slices][2] -- what ``bn.bn_train(..., stats=...)`` needs instead of a pass over y."""
-    return _Conv3x3.apply(x, w, want_stats)
+    src_y, src_saved = _bnlink.source_of(x) if (x.requires_grad and w.requires_grad) else (None, None)
+    return _Conv3x3.apply(x, w, want_stats, src_y, src_saved)
 
 
 # ------------------------------------------------------------------ the down-sampling block's pair

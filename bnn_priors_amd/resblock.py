@@ -24,6 +24,7 @@ import os
 import torch
 
 from . import _hip
+from . import bnlink as _bnlink
 from . import conv as _conv
 
 ENABLED = os.environ.get("SGMCMC_BLOCK", "1") != "0"
@@ -33,6 +34,13 @@ ENABLED = os.environ.get("SGMCMC_BLOCK", "1") != "0"
 # launch saves, so that shape keeps the two-launch BatchNorm backward (and only fuses the shortcut's add).
 FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") == "" else \
     {tuple(int(v) for v in item.split("x")) for item in os.environ["SGMCMC_BLOCK_FUSED"].split(",") if item}
+# The route that replaced it (default): the BatchNorm backward's SUMS come out of the epilogue of the
+# convolution-gradient launch that produces the BatchNorm's incoming gradient (``sgmcmc_conv3x3_bwd_ex``), so a
+# BatchNorm backward is the dx launch alone and a block's backward is four launches whatever the shape:
+#     [sums(bn2): epilogue of the NEXT block's conv1 gradient, else its own launch]
+#     dx(bn2) -> conv2 gradients [+ sums(bn1)] -> dx(bn1) -> conv1 gradients [+ dout*[out>0]] [+ sums(previous bn2)]
+# SGMCMC_BLOCK_EPILOGUE_SUMS=0 restores the routes above.
+EPILOGUE_SUMS = os.environ.get("SGMCMC_BLOCK_EPILOGUE_SUMS", "1") != "0"
 
 
 def supported(x, conv1, bn1, conv2, bn2):
@@ -141,38 +149,104 @@ def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
     return dx, _reduce_or_defer(lib, w, part, slabs.value, s)
 
 
+def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s):
+    "dy of out = relu(bn(y) [+ r]) given dout and the channel sums' partials; dgb [2][C] <- dgamma, dbeta"
+    n, c, hw = y.shape[0], y.shape[1], y.shape[2]
+    dy = torch.empty_like(y)
+    err = lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
+                               saved[1].data_ptr(), 1, n, c, hw * hw, partial.data_ptr(), n_partials, dy.data_ptr(), 0,
+                               dgb[0].data_ptr(), dgb[1].data_ptr(), s)
+    if err:
+        _hip.check(err, "sgmcmc_bn_bwd_dx")
+    return dy
+
+
+def _bn_sums(lib, dout, out, y, saved, s):
+    "the sums launch on its own -> (partial, n_partials)"
+    n, c, hw = y.shape[0], y.shape[1], y.shape[2]
+    sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=y.device)
+    n_sums = ctypes.c_int(0)
+    err = lib.sgmcmc_bn_bwd_sums(dout.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
+                                 saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s)
+    if err:
+        _hip.check(err, "sgmcmc_bn_bwd_sums")
+    return sums, n_sums.value
+
+
+def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None):
+    """both gradients of y = conv3x3(x, w) given dy; ``add`` = (e_dout, e_out): dx += e_dout * [e_out > 0];
+    ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward whose incoming gradient
+    dx is -> (dx, dw, partial or None, n_partials)"""
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    E = _hip.ConvBwdEpilogue()
+    if add is not None:
+        E.e_dout, E.e_out = add[0].data_ptr(), add[1].data_ptr()
+    partial, n_partials = None, lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
+    if sums_for is not None:
+        y_bn, out_bn, saved_bn = sums_for
+        partial = torch.empty((c, n_partials, 2), dtype=torch.float64, device=x.device)
+        E.s_y, E.s_out, E.s_mean, E.s_invstd = y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(), saved_bn[1].data_ptr()
+        E.s_partial = partial.data_ptr()
+    slabs = ctypes.c_int(0)
+    err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E), 0,
+                                    part.data_ptr(), n, c, hw, ctypes.byref(slabs), s)
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_bwd_ex")
+    return dx, _reduce_or_defer(lib, w, part, slabs.value, s), partial, n_partials
+
+
 class _Block(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, mom1, eps1, mom2, eps2):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, mom1, eps1, mom2, eps2, src_y, src_saved):
         lib = _hip.lib()
         _conv._note_use(w1, w2)
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         s = _stream()
         y1, h, saved1 = _conv_bn_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, None, s)
         y2, out, saved2 = _conv_bn_fwd(lib, h, w2, g2, b2, rm2, rv2, mom2, eps2, x, s)
-        ctx.save_for_backward(x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2)
-        return out
+        ctx.save_for_backward(x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved)
+        ctx.mark_non_differentiable(y2, saved2)
+        ctx.set_materialize_grads(False)
+        return out, y2, saved2        # (y2, saved2: where `out` came from, for the next operator -- bnlink)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_):
         lib = _hip.lib()
-        x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2 = ctx.saved_tensors
+        x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved = ctx.saved_tensors
+        if dout is None:
+            return (None,) * 17
+        up = _bnlink.sums_of(dout) if EPILOGUE_SUMS else None
         dout = dout.contiguous()
         s = _stream()
         dgb = torch.empty((2, 2, x.shape[1]), dtype=torch.float32, device=x.device)
-        if (x.shape[1], x.shape[2]) in FUSED_BN_BWD:
+        if EPILOGUE_SUMS:
+            # bn2's sums: left by the launch that produced dout (the next block's conv1 gradient), else a launch here
+            sums2, n2 = up if up is not None else _bn_sums(lib, dout, out, y2, saved2, s)
+            dy2 = _bn_dx(lib, dout, out, y2, saved2, g2, dgb[1], sums2, n2, s)
+            dh, dw2, sums1, n1 = _conv_bwd_ex(lib, h, w2, dy2, s, sums_for=(y1, h, saved1))
+            dy1 = _bn_dx(lib, dh, h, y1, saved1, g1, dgb[0], sums1, n1, s)
+            # ... and this block's input came out of a BatchNorm + ReLU too: its sums ride in conv1's gradient launch
+            dx, dw1, sums0, n0 = _conv_bwd_ex(lib, x, w1, dy1, s, add=(dout, out),
+                                              sums_for=None if src_y is None else (src_y, x, src_saved))
+            if sums0 is not None:
+                _bnlink.tag_gradient(dx, sums0, n0)
+        elif (x.shape[1], x.shape[2]) in FUSED_BN_BWD:
             dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
             # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue
             dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
         else:
             dh, dw2 = _conv_bn_bwd_two_launch(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
             dx, dw1 = _conv_bn_bwd_two_launch(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
-        return (dx, dw1, dgb[0, 0], dgb[0, 1], dw2, dgb[1, 0], dgb[1, 1]) + (None,) * 8
+        return (dx, dw1, dgb[0, 0], dgb[0, 1], dw2, dgb[1, 0], dgb[1, 1]) + (None,) * 10
 
 
 def residual_block(x, conv1, bn1, conv2, bn2):
     "relu(bn2(conv2(relu(bn1(conv1(x))))) + x) for modules that pass ``supported``"
-    return _Block.apply(x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias,
-                        bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
-                        bn1.momentum, bn1.eps, bn2.momentum, bn2.eps)
+    src_y, src_saved = _bnlink.source_of(x) if (EPILOGUE_SUMS and x.requires_grad) else (None, None)
+    out, y2, saved2 = _Block.apply(x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias,
+                                   bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
+                                   bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, src_y, src_saved)
+    return _bnlink.tag_output(out, y2, saved2)

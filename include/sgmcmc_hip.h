@@ -400,6 +400,21 @@ int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* d
 int sgmcmc_conv3x3_bwd_add(const float* x, const float* w, const float* dy, float* dx, const float* e_dout,
                            const float* e_out, float* dw, float* scratch, int n_img, int channels, int hw,
                            int* deferred_slabs, void* stream);
+/* The general form: the data gradient's epilogue may add the shortcut's gradient (e_dout / e_out, both or neither)
+ * and / or leave the partial sums of the BatchNorm backward that CONSUMES dx as its incoming gradient (s_*: that
+ * BatchNorm's input y, its post-ReLU output, its saved mean / invstd): s_partial[(c * S + slice) * 2 + {0,1}] =
+ * sum dz, sum dz * xhat over the slice, dz = dx * [s_out > 0], xhat = (s_y - mean_c) * invstd_c, S =
+ * sgmcmc_conv3x3_stat_slices(n_img, channels, hw) slices per channel -- what sgmcmc_bn_bwd_sums would compute in a
+ * launch of its own (same quantities, another summation grouping); feed them to sgmcmc_bn_bwd_dx.
+ * Replaces BatchNorm2d's backward reductions (models/google_resnet.py:34-43 inside inference.py:215-223). */
+typedef struct {
+  const float *e_dout, *e_out;
+  const float *s_y, *s_out, *s_mean, *s_invstd;
+  double* s_partial;
+} sgmcmc_conv_bwd_epilogue;
+int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float* dx,
+                          const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
+                          int hw, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;
@@ -468,6 +483,12 @@ int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const f
                         const float* save_mean, const float* save_invstd, int relu, int n, int channels,
                         int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,
                         double* scratch, void* stream);
+/* The second launch of sgmcmc_bn_train_bwd alone, for partial sums that already exist: `partial` =
+ * [channels][n_partials][2] doubles (sum dz, sum dz * xhat per slice) from sgmcmc_bn_bwd_sums or from the epilogue of
+ * the convolution gradient that produced dy (sgmcmc_conv3x3_bwd_ex). */
+int sgmcmc_bn_bwd_dx(const float* dy, const float* y, const float* x, const float* gamma, const float* save_mean,
+                     const float* save_invstd, int relu, int n, int channels, int plane, const double* partial,
+                     int n_partials, float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream);
 
 /* y = maxpool2x2(relu(x + bias_c)), NCHW fp32, h and w even: the Conv2d(+bias) -> ReLU -> MaxPool2d(2) tail
  * of models/conv_nets.py:44-56 in one pass (the convolution itself is then run without its bias).

@@ -60,13 +60,23 @@ def _run(blk, x, dout):
     return out.detach(), xs.grad, {k: v.clone() for k, v in grads.items()}
 
 
-@pytest.mark.parametrize("fused_bwd", [True, False])
+def _route(monkeypatch, route):
+    """the three backward routes, at every shape: BatchNorm-backward sums from the convolution gradient's epilogue
+    (default) / BatchNorm backward inside the convolution-gradient launch / as two launches of its own"""
+    from bnn_priors_amd import resblock
+    monkeypatch.setattr(resblock, "EPILOGUE_SUMS", route == "epilogue_sums")
+    monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES) if route == "fused" else set())
+
+
+ROUTES = ["epilogue_sums", "fused", "two_launch"]
+
+
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
-def test_fused_block_matches_float64_reference(c, hw, n, fused_bwd, monkeypatch):
+def test_fused_block_matches_float64_reference(c, hw, n, route, monkeypatch):
     from bnn_priors_amd import resblock
-    # both backward routes at every shape: BatchNorm backward inside the convolution-gradient launch / as two launches
-    monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES) if fused_bwd else set())
+    _route(monkeypatch, route)
     blk = _block(c)
     blk.train()
     g = torch.Generator().manual_seed(100 * c + n)
@@ -88,10 +98,11 @@ def test_fused_block_matches_float64_reference(c, hw, n, fused_bwd, monkeypatch)
         torch.testing.assert_close(grads[k].double(), ref_g[k], rtol=2e-3, atol=3e-4 * scale(ref_g[k])), k
 
 
+@pytest.mark.parametrize("route", ROUTES[:2])
 @pytest.mark.parametrize("c,hw", SHAPES)
-def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, monkeypatch):
+def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, route, monkeypatch):
     from bnn_priors_amd import resblock
-    monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES))
+    _route(monkeypatch, route)
     g = torch.Generator().manual_seed(c)
     x = torch.relu(torch.randn(64, c, hw, hw, generator=g)).cuda()
     dout = torch.randn(64, c, hw, hw, generator=g).cuda()
@@ -128,3 +139,47 @@ def test_eval_mode_and_off_table_shapes_take_the_layered_path():
     blk.train()
     assert not resblock.supported(torch.randn(4, 16, 16, 16).cuda(), blk.main[0], blk.main[1], blk.main[3], blk.main[4])
     assert resblock.supported(x, blk.main[0], blk.main[1], blk.main[3], blk.main[4])
+
+
+def test_batchnorm_backward_sums_ride_in_the_upstream_convolution_gradient(monkeypatch):
+    """googleresnet (depth 20), one forward + backward: of the 19 BatchNorm + ReLU layers, 16 take their backward
+    sums from the epilogue of the convolution gradient that produced their incoming gradient -- the 7 first
+    BatchNorms of the identity blocks inside their block, 9 across operators (bnlink tags: stem, the down-sampling
+    blocks' main BatchNorms, 4 identity blocks' second) -- and 3 launch their own (their gradient comes from a
+    down-sampling pair or the head).  Gradients agree with the route switched off."""
+    from bnn_priors_amd import bnlink, models
+    torch.manual_seed(0)
+    x = torch.randn(16, 3, 32, 32).cuda()
+    y = torch.randint(0, 10, (16,)).cuda()
+    net = models.get_model(x.cpu()[:2], y.cpu()[:2], "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    models.he_initialize(net)
+    net.train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def grads():
+        net.load_state_dict(state)
+        for p in net.parameters():
+            p.grad = None
+        loss = torch.nn.functional.cross_entropy(net.net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), [p.grad.clone() for p in net.parameters()]
+
+    bnlink.STATS.update(upstream=0, own=0)
+    loss1, g1 = grads()
+    assert bnlink.STATS == {"upstream": 9, "own": 3}, bnlink.STATS
+    monkeypatch.setattr(bnlink, "ENABLED", False)
+    bnlink.STATS.update(upstream=0, own=0)
+    loss0, g0 = grads()
+    assert bnlink.STATS["upstream"] == 0
+    assert loss0 == loss1
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5 * max(1.0, b.abs().max().item()))
+    # a gradient tensor that was touched after its producer tagged it is not trusted
+    t = torch.zeros(4, device="cuda")
+    monkeypatch.setattr(bnlink, "ENABLED", True)
+    bnlink.tag_gradient(t, torch.zeros(1), 1)
+    assert bnlink.sums_of(t) is not None
+    t.add_(1.0)
+    assert bnlink.sums_of(t) is None

@@ -36,12 +36,24 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
                            invstd=saved[1].data_ptr(), gamma=gamma.data_ptr(), sums=sums.data_ptr(),
                            n_sums=n_sums.value, reserved=0, dgamma=dgb[0].data_ptr(), dbeta=dgb[1].data_ptr(),
                            e_dout=0, e_out=0)
+    part = torch.empty((c, slices, 2), dtype=torch.float64, device=dev)
+    E_s, E_a, E_as = _hip.ConvBwdEpilogue(), _hip.ConvBwdEpilogue(), _hip.ConvBwdEpilogue()
+    for E in (E_s, E_as):
+        E.s_y, E.s_out, E.s_mean, E.s_invstd, E.s_partial = y.data_ptr(), out.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), part.data_ptr()
+    for E in (E_a, E_as):
+        E.e_dout, E.e_out = dy.data_ptr(), out.data_ptr()
     cases = {
         "fwd+stats": lambda: lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s),
         "dgrad": lambda: lib.sgmcmc_conv3x3(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, c, hw, 1, 0, s),
         "wrw(first launch)": lambda: lib.sgmcmc_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n, c, hw, s),
         "bwd": lambda: lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, scratch.data_ptr(),
                                               n, c, hw, ctypes.byref(slabs), s),
+        "bwd+sums": lambda: lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E_s), 0,
+                                                      scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s),
+        "bwd+add": lambda: lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E_a), 0,
+                                                     scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s),
+        "bwd+add+sums": lambda: lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E_as), 0,
+                                                          scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s),
         "bn_bwd": lambda: lib.sgmcmc_conv3x3_bn_bwd(x.data_ptr(), w.data_ptr(), dx.data_ptr(), scratch.data_ptr(),
                                                     ctypes.byref(A), n, c, hw, ctypes.byref(slabs), s),
         "bn_bwd_sums": lambda: lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
