@@ -82,6 +82,11 @@ class ConvBwdEpilogue(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
 
 
+class BnResidualSums(ctypes.Structure):
+    "sgmcmc_bn_residual_sums"
+    _fields_ = [(n, ctypes.c_void_p) for n in ("y", "mean", "invstd", "partial")]
+
+
 class ConvBnBwdArgs(ctypes.Structure):
     "sgmcmc_conv_bn_bwd_args"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("dout", "mask_out", "y", "mean", "invstd", "gamma", "sums")]
@@ -215,8 +220,11 @@ EXPORTS = {
                                + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
                               + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv_down_bwd_sum_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv_down_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ConvBwdEpilogue)]
+                                + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_bn_bwd_dx": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
-                         + [ctypes.c_void_p] * 5),
+                         + [ctypes.c_void_p] * 4 + [ctypes.POINTER(BnResidualSums), ctypes.c_void_p]),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
     "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3

@@ -8,6 +8,7 @@ residual.  Two launches forward (one when the producing convolution hands over t
 backward, deterministic statistics (no atomics).
 Reference: the BatchNorm layers of bnn_priors/models/google_resnet.py:34-43, 77-90.
 """
+import ctypes
 import os
 
 import torch
@@ -30,7 +31,8 @@ def _ptr(t):
 
 class _BNTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats_in):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats_in,
+                res_y=None, res_saved=None):
         lib = _hip.lib()
         x = x.contiguous()
         if residual is not None:
@@ -53,7 +55,7 @@ class _BNTrain(torch.autograd.Function):
                                       torch.cuda.current_stream().cuda_stream)
         if err:
             _hip.check(err, "sgmcmc_bn_train_fwd")
-        ctx.save_for_backward(x, weight, y if relu else None, stats)
+        ctx.save_for_backward(x, weight, y if relu else None, stats, res_y, res_saved)
         ctx.relu, ctx.has_residual = bool(relu), residual is not None
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)
@@ -63,11 +65,11 @@ class _BNTrain(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, *_):
         lib = _hip.lib()
-        x, weight, y, stats = ctx.saved_tensors
+        x, weight, y, stats, res_y, res_saved = ctx.saved_tensors
         if dy is None:
-            return (None,) * 10
+            return (None,) * 12
         # the launch that produced dy may have left this BatchNorm's channel sums with it (bnlink)
-        up = _bnlink.sums_of(dy) if ctx.relu else None
+        up = _bnlink.sums_of(dy)
         dy = dy.contiguous()
         n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
         dx = torch.empty_like(x)
@@ -77,14 +79,32 @@ class _BNTrain(torch.autograd.Function):
         else:
             dres = torch.empty_like(x) if want_res else None
         dwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        if up is not None:
+        st = torch.cuda.current_stream().cuda_stream
+        # the residual is a ReLU-less BatchNorm's output (the down-sampling shortcut): its sums ride in the dx launch
+        rsums = res_y is not None and want_res and ctx.relu
+        if up is not None or rsums:
+            if up is None:
+                sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+                n_sums = ctypes.c_int(0)
+                err = lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), _ptr(y), x.data_ptr(), stats[0].data_ptr(),
+                                             stats[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, plane, st)
+                if err:
+                    _hip.check(err, "sgmcmc_bn_bwd_sums")
+                up = (sums, n_sums.value)
+            R = None
+            if rsums:
+                r_part = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+                R = _hip.BnResidualSums(y=res_y.data_ptr(), mean=res_saved[0].data_ptr(),
+                                        invstd=res_saved[1].data_ptr(), partial=r_part.data_ptr())
             err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(), stats[0].data_ptr(),
-                                       stats[1].data_ptr(), 1, n, c, plane, up[0].data_ptr(), up[1], dx.data_ptr(),
-                                       0 if dres is dy else _ptr(dres), dwb[0].data_ptr(), dwb[1].data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+                                       stats[1].data_ptr(), int(ctx.relu), n, c, plane, up[0].data_ptr(), up[1],
+                                       dx.data_ptr(), 0 if dres is dy else _ptr(dres), dwb[0].data_ptr(),
+                                       dwb[1].data_ptr(), None if R is None else ctypes.byref(R), st)
             if err:
                 _hip.check(err, "sgmcmc_bn_bwd_dx")
-            return dx, dwb[0], dwb[1], dres, None, None, None, None, None, None
+            if rsums:
+                _bnlink.tag_gradient(dres, r_part, r_part.numel() // (2 * c))
+            return (dx, dwb[0], dwb[1], dres) + (None,) * 8
         scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
         err = lib.sgmcmc_bn_train_bwd(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(),
                                       stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu), n, c, plane,
@@ -93,14 +113,18 @@ class _BNTrain(torch.autograd.Function):
                                       torch.cuda.current_stream().cuda_stream)
         if err:
             _hip.check(err, "sgmcmc_bn_train_bwd")
-        return dx, dwb[0], dwb[1], dres, None, None, None, None, None, None
+        return (dx, dwb[0], dwb[1], dres) + (None,) * 8
 
 
 def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, stats=None):
     """``stats``: per-slice partial (sum, sum of squared deviations from the slice mean) of x over equal parts of (N, H, W) per channel, float64
     [channels][slices][2], if the producer of x already has them (``conv.conv3x3(..., want_stats=True)``);
     the statistics pass over x is skipped then."""
-    out, saved = _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)
+    res_y, res_saved = _bnlink.linear_source_of(residual) if relu else (None, None)
+    out, saved = _BNTrain.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats,
+                                res_y, res_saved)
     if relu:      # a convolution that consumes `out` can produce this BatchNorm's backward sums (bnlink)
         _bnlink.tag_output(out, x, saved)
+    elif residual is None:
+        _bnlink.tag_linear_output(out, x, saved)
     return out

@@ -35,6 +35,20 @@ def source_of(x):
     return src
 
 
+def tag_linear_output(out, bn_input, saved):
+    "out = bn(bn_input) without ReLU (a down-sampling block's shortcut): a BatchNorm that takes it as residual can sum for it"
+    if ENABLED:
+        out._sgmcmc_bn_src_lin = (bn_input.detach(), saved)
+    return out
+
+
+def linear_source_of(r):
+    src = getattr(r, "_sgmcmc_bn_src_lin", None) if (ENABLED and r is not None) else None
+    if src is None or src[0].shape != r.shape or not src[0].is_contiguous():
+        return None, None
+    return src
+
+
 def tag_gradient(dx, partial, n_partials):
     dx._sgmcmc_bn_sums = (partial, n_partials, dx._version, dx.data_ptr())
     return dx

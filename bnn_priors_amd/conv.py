@@ -211,7 +211,7 @@ def down_supported(x, w_main, w_short):
 
 class _ConvDown(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_main, w_short, want_stats):
+    def forward(ctx, x, w_main, w_short, want_stats, src_y=None, src_saved=None):
         lib = _hip.lib()
         _note_use(w_main, w_short)
         x, w_main, w_short = x.contiguous(), w_main.contiguous(), w_short.contiguous()
@@ -228,7 +228,7 @@ class _ConvDown(torch.autograd.Function):
                                        0 if ss is None else ss.data_ptr(), n, c, hw, _stream())
         if err:
             _hip.check(err, "sgmcmc_conv_down_fwd")
-        ctx.save_for_backward(x, w_main, w_short)
+        ctx.save_for_backward(x, w_main, w_short, src_y, src_saved)
         ctx.set_materialize_grads(False)
         if not want_stats:
             return ym, ys
@@ -239,9 +239,9 @@ class _ConvDown(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dym, dys, *_):
         lib = _hip.lib()
-        x, w_main, w_short = ctx.saved_tensors
+        x, w_main, w_short, src_y, src_saved = ctx.saved_tensors
         if dym is None and dys is None:
-            return None, None, None, None
+            return None, None, None, None, None, None
         n_, c_, hw_ = x.shape[0], x.shape[1], x.shape[2]
         zeros = lambda: torch.zeros((n_, 2 * c_, hw_ // 2, hw_ // 2), dtype=torch.float32, device=x.device)
         dym = zeros() if dym is None else dym.contiguous()
@@ -254,24 +254,36 @@ class _ConvDown(torch.autograd.Function):
         slabs = ctypes.c_int(0)
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
-        err = lib.sgmcmc_conv_down_bwd(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
-                                       dys.data_ptr(), dx.data_ptr(), dwm.data_ptr(), dws.data_ptr(),
-                                       scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None,
-                                       _stream())
+        if src_y is None:
+            err = lib.sgmcmc_conv_down_bwd(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
+                                           dys.data_ptr(), dx.data_ptr(), dwm.data_ptr(), dws.data_ptr(),
+                                           scratch.data_ptr(), n, c, hw, ctypes.byref(slabs) if defer else None,
+                                           _stream())
+        else:       # x came out of a BatchNorm + ReLU: that BatchNorm's backward sums ride in this launch (bnlink)
+            n_part = lib.sgmcmc_conv_down_bwd_sum_slices(n, c, hw)
+            partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
+            E = _hip.ConvBwdEpilogue(s_y=src_y.data_ptr(), s_out=x.data_ptr(), s_mean=src_saved[0].data_ptr(),
+                                     s_invstd=src_saved[1].data_ptr(), s_partial=partial.data_ptr())
+            err = lib.sgmcmc_conv_down_bwd_ex(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
+                                              dys.data_ptr(), dx.data_ptr(), ctypes.byref(E), dwm.data_ptr(),
+                                              dws.data_ptr(), scratch.data_ptr(), n, c, hw,
+                                              ctypes.byref(slabs) if defer else None, _stream())
+            _bnlink.tag_gradient(dx, partial, n_part)
         if err:
             _hip.check(err, "sgmcmc_conv_down_bwd")
         if defer:   # scratch = [slabs][dwm.numel()] then [slabs][dws.numel()]
             _pending.append((scratch, dwm, slabs.value, 9))
             _pending.append((scratch[slabs.value * dwm.numel():], dws, slabs.value, 1))
-            return dx, dwm.view(dwm.shape), dws.view(dws.shape), None
-        return dx, dwm, dws, None
+            return dx, dwm.view(dwm.shape), dws.view(dws.shape), None, None, None
+        return dx, dwm, dws, None, None, None
 
 
 def conv_down(x, w_main, w_short, want_stats=False):
     """(conv2d(x, w_main, stride=2, padding=1), conv2d(x, w_short, stride=2)) in one operator, for the
     (channels, side) pairs in DOWN_SHAPES; with ``want_stats`` also the two outputs' batch statistics
     (see ``conv3x3``)."""
-    return _ConvDown.apply(x, w_main, w_short, want_stats)
+    src_y, src_saved = _bnlink.source_of(x) if x.requires_grad else (None, None)
+    return _ConvDown.apply(x, w_main, w_short, want_stats, src_y, src_saved)
 
 
 # ------------------------------------------------------------------ the stem

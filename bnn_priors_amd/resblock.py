@@ -155,7 +155,7 @@ def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s):
     dy = torch.empty_like(y)
     err = lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
                                saved[1].data_ptr(), 1, n, c, hw * hw, partial.data_ptr(), n_partials, dy.data_ptr(), 0,
-                               dgb[0].data_ptr(), dgb[1].data_ptr(), s)
+                               dgb[0].data_ptr(), dgb[1].data_ptr(), None, s)
     if err:
         _hip.check(err, "sgmcmc_bn_bwd_dx")
     return dy

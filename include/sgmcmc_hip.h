@@ -436,6 +436,13 @@ int64_t sgmcmc_conv_down_scratch_floats(int n_img, int cin, int hwi);
 int sgmcmc_conv_down_bwd(const float* x, const float* w_main, const float* w_short, const float* dy_main,
                          const float* dy_short, float* dx, float* dw_main, float* dw_short, float* scratch,
                          int n_img, int cin, int hwi, int* deferred_slabs, void* stream);
+/* ... with the SUMS half of sgmcmc_conv_bwd_epilogue (e_dout / e_out must be NULL): the partial sums of the BatchNorm
+ * backward whose incoming gradient dx is, [cin][sgmcmc_conv_down_bwd_sum_slices(...)][2] doubles. */
+int sgmcmc_conv_down_bwd_sum_slices(int n_img, int cin, int hwi);
+int sgmcmc_conv_down_bwd_ex(const float* x, const float* w_main, const float* w_short, const float* dy_main,
+                            const float* dy_short, float* dx, const sgmcmc_conv_bwd_epilogue* epi, float* dw_main,
+                            float* dw_short, float* scratch, int n_img, int cin, int hwi, int* deferred_slabs,
+                            void* stream);
 
 /* The stem convolution, 3 -> 16 channels, 3x3 / stride 1 / pad 1 on 32x32 images (google_resnet.py:96-100):
  * forward (+ optional per-band statistics [16][4 n_img][2]) and weight gradient (the images take no
@@ -486,9 +493,18 @@ int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const f
 /* The second launch of sgmcmc_bn_train_bwd alone, for partial sums that already exist: `partial` =
  * [channels][n_partials][2] doubles (sum dz, sum dz * xhat per slice) from sgmcmc_bn_bwd_sums or from the epilogue of
  * the convolution gradient that produced dy (sgmcmc_conv3x3_bwd_ex). */
+/* rs (may be NULL; needs relu and dresidual): the residual is itself the output of a BatchNorm WITHOUT ReLU (the
+ * down-sampling block's shortcut, models/google_resnet.py:77-90) whose incoming gradient is dresidual; the launch
+ * also leaves that BatchNorm's backward sums in rs->partial, [channels][sgmcmc_bn_scratch_doubles(...) / (2
+ * channels)][2] doubles (the slices of this launch's own geometry). */
+typedef struct {
+  const float *y, *mean, *invstd; /* the residual BatchNorm's input and saved statistics */
+  double* partial;
+} sgmcmc_bn_residual_sums;
 int sgmcmc_bn_bwd_dx(const float* dy, const float* y, const float* x, const float* gamma, const float* save_mean,
                      const float* save_invstd, int relu, int n, int channels, int plane, const double* partial,
-                     int n_partials, float* dx, float* dresidual, float* dgamma, float* dbeta, void* stream);
+                     int n_partials, float* dx, float* dresidual, float* dgamma, float* dbeta,
+                     const sgmcmc_bn_residual_sums* rs, void* stream);
 
 /* y = maxpool2x2(relu(x + bias_c)), NCHW fp32, h and w even: the Conv2d(+bias) -> ReLU -> MaxPool2d(2) tail
  * of models/conv_nets.py:44-56 in one pass (the convolution itself is then run without its bias).
