@@ -6,17 +6,21 @@ Reference: ``BasicBlock`` with the identity shortcut, bnn_priors/models/google_r
 gradient evaluation of inference.py:215-223.
 
 Forward: the same four launches as the layer-by-layer path (``conv.conv3x3`` with the batch statistics from its
-epilogue, ``bn.bn_train``).  Backward: FOUR launches instead of seven + an ATen add -- each BatchNorm's
-data-gradient pass lives inside the following convolution-gradient launch, which forms
-``dy = k (dz - mean dz - xhat mean(dz xhat))`` while it stages its operands (``csrc/conv_fused_hip.inc``,
-``sgmcmc_conv3x3_bn_bwd``), and the shortcut's gradient is added in the first convolution's data-gradient epilogue:
+epilogue, ``bn.bn_train``).  Backward: FOUR launches (the layered path: seven + an ATen add):
 
-    sums(bn2)  ->  conv2 gradients [bn2 backward while staging]  ->  sums(bn1)
-               ->  conv1 gradients [bn1 backward while staging, + dout*[out>0] in the epilogue]
+    dx(bn2)  ->  conv2 gradients [+ sums(bn1) in the data gradient's epilogue]
+             ->  dx(bn1)  ->  conv1 gradients [+ dout*[out>0], + sums(previous BatchNorm) in the epilogue]
 
-(Finishing the sums inside the producing launch by a last-arriver ticket was built and measured: 7-12 us per hand-off
-on MI355X against ~1.5 us for a kernel boundary -- DESIGN.md.)  Training mode only; anything else takes the
-layer-by-layer path (``models/nets.py``).
+A BatchNorm backward needs two per-channel sums over the batch before its element-wise pass.  They are left, per
+workgroup band, by the epilogue of the convolution-gradient launch that PRODUCES the BatchNorm's incoming gradient
+(``sgmcmc_conv3x3_bwd_ex``, csrc/conv_hip.inc ``band_sums``) -- inside the block for bn1, and across operators for
+bn2 through ``bnlink`` tags (the next block's conv1 gradient, a down-sampling pair's data gradient); only a
+BatchNorm whose gradient comes from somewhere else (the head) launches ``sgmcmc_bn_bwd_sums`` itself.
+Alternatives kept behind switches, both measured slower: the BatchNorm backward formed inside the
+convolution-gradient launch while it stages its operands (``FUSED_BN_BWD`` / ``sgmcmc_conv3x3_bn_bwd``: its prologue
+needs few partials per channel, so it cannot take epilogue sums) and finishing the sums inside the producing launch
+by a last-arriver ticket (7-12 us per hand-off on MI355X against ~1.5 us for a kernel boundary -- DESIGN.md).
+Training mode only; anything else takes the layer-by-layer path (``models/nets.py``).
 """
 import ctypes
 import os
