@@ -180,7 +180,8 @@ def conv_rooflines(device, n_img=128, iters=60):
     ``fused_bwd_kernel`` (BatchNorm backward formed while staging) for the shapes whose blocks take that route
     (resblock.FUSED_BN_BWD) -- launched through the C ABI on synthetic tensors with the same shapes as in the step.
     Algorithmic flops: 2 * N * HW^2 * C^2 * 9 per convolution-shaped contraction (forward: one; backward: two).
-    ``launches_per_step``: how often googleresnet's step runs the kernel (6 + 5 + 5 trunk convolutions)."""
+    ``launches_per_step``: how often googleresnet's step runs the kernel (6 + 5 + 5 trunk convolutions; 0 = an
+    alternative route, timed for comparison)."""
     from bnn_priors_amd import _hip, resblock
     lib = _hip.lib()
     stream = torch.cuda.current_stream(device).cuda_stream
@@ -207,7 +208,10 @@ def conv_rooflines(device, n_img=128, iters=60):
                                invstd=saved[1].data_ptr(), gamma=gamma.data_ptr(), sums=sums.data_ptr(),
                                n_sums=n_sums.value, reserved=0, dgamma=dgb[0].data_ptr(), dbeta=dgb[1].data_ptr(),
                                e_dout=0, e_out=0)
-        fused_route = (c, hw) in resblock.FUSED_BN_BWD
+        fused_route = (not resblock.EPILOGUE_SUMS) and (c, hw) in resblock.FUSED_BN_BWD
+        part = torch.empty((c, lib.sgmcmc_conv3x3_stat_slices(n_img, c, hw), 2), dtype=torch.float64, device=device)
+        E = _hip.ConvBwdEpilogue(s_y=y.data_ptr(), s_out=out.data_ptr(), s_mean=saved[0].data_ptr(),
+                                 s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr())
         n_convs = 6 if c == 16 else 5          # trunk convolutions of this shape in googleresnet (depth 20)
 
         def fwd():
@@ -218,6 +222,11 @@ def conv_rooflines(device, n_img=128, iters=60):
             _hip.check(lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(),
                                               dw.data_ptr(), scratch.data_ptr(), n_img, c, hw,
                                               ctypes.byref(slabs), stream), "sgmcmc_conv3x3_bwd")
+        def bwd_sums():     # as the step runs it: the next BatchNorm backward's sums in the data gradient's epilogue
+            _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
+                                                 dw.data_ptr(), scratch.data_ptr(), n_img, c, hw, ctypes.byref(slabs),
+                                                 stream), "sgmcmc_conv3x3_bwd_ex")
+
         def bn_bwd():
             _hip.check(lib.sgmcmc_conv3x3_bn_bwd(x.data_ptr(), w.data_ptr(), dx.data_ptr(), scratch.data_ptr(),
                                                  ctypes.byref(A), n_img, c, hw, ctypes.byref(slabs), stream),
@@ -225,7 +234,8 @@ def conv_rooflines(device, n_img=128, iters=60):
         # (the down-sampling block's second convolution has no identity-shortcut block around it: plain route)
         for name, fn, flops, per_step in (
                 (f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1, n_convs),
-                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1, n_convs if not fused_route else 1),
+                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1, 0),
+                (f"conv::conv3x3_bwd_kernel<{c},{hw},8,SUMS>", bwd_sums, 2 * flop1, n_convs if not fused_route else 1),
                 (f"conv::fused_bwd_kernel<{c},{hw},8>", bn_bwd, 2 * flop1, n_convs - 1 if fused_route else 0)):
             for _ in range(5):
                 fn()
