@@ -1,6 +1,6 @@
 """The trunk's convolution kernels alone, for counter-only rocprofv3 passes (tools/pmc_hbm.sh, tools/pmc_mfma.sh):
-each shape's forward (conv3x3 + statistics), plain backward (conv3x3_bwd) and BatchNorm-fused backward
-(conv3x3_bn_bwd) launched a few times through the C ABI on synthetic tensors of the step's shapes.
+each shape's forward (conv3x3 + statistics), backward (conv3x3_bwd, plain and with the sums epilogue the step uses)
+and the alternative BatchNorm-fused backward (conv3x3_bn_bwd) launched a few times through the C ABI on synthetic tensors of the step's shapes.
     python tools/conv_pmc.py [--iters 6] [--n 128]"""
 import argparse
 import ctypes
@@ -30,10 +30,15 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     saved = torch.stack([torch.zeros(c, device=dev), torch.ones(c, device=dev)])
     gamma, dgb = torch.ones(c, device=dev), torch.empty((2, c), device=dev)
     slabs, n_sums = ctypes.c_int(0), ctypes.c_int(0)
+    part = torch.empty((c, slices, 2), dtype=torch.float64, device=dev)
     for _ in range(a.iters):
         _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s), "fwd")
         _hip.check(lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, scratch.data_ptr(),
                                           n, c, hw, ctypes.byref(slabs), s), "bwd")
+        E = _hip.ConvBwdEpilogue(s_y=y.data_ptr(), s_out=out.data_ptr(), s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(),
+                                 s_partial=part.data_ptr())
+        _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E), 0,
+                                             scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s), "bwd_ex")    # as the step runs it
         _hip.check(lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
                                           saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s), "sums")
         A = _hip.ConvBnBwdArgs(dout=dy.data_ptr(), mask_out=out.data_ptr(), y=y.data_ptr(), mean=saved[0].data_ptr(),

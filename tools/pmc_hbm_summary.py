@@ -42,14 +42,16 @@ def algorithmic_bytes(name, grid):
         n = grid // 256 // ((hw // 8) * (c // 16))
         act = 4 * n * c * hw * hw
         return act + 36 * c * c, act
-    m = re.search(r"conv3x3_bwd_kernel<(\d+), (\d+), (\d+)>", name)
+    m = re.search(r"conv3x3_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", name)
     if m:
         c, hw = int(m.group(1)), int(m.group(2))
         # grid = dgrad blocks (n * bands * ct) + wrw blocks (n * bands / 2 * ct)
         n = grid // 256 * 2 // (3 * (hw // 8) * (c // 16))
         act = 4 * n * c * hw * hw
         slabs = n * (hw // 8) // 2
-        return 2 * act + 36 * c * c, act + 36 * c * c * slabs       # reads x, dy, w; writes dx + partial slabs
+        extra = (2 * act if m.group(4) == "true" else 0) + (2 * act if m.group(5) == "true" else 0)   # epilogue operands
+        # reads x, dy, w (+ the shortcut's dout / out, + the next BatchNorm's y / out); writes dx + partial slabs
+        return 2 * act + 36 * c * c + extra, act + 36 * c * c * slabs
     m = re.search(r"fused_bwd_kernel<(\d+), (\d+), (\d+), (true|false)>", name)
     if m:
         c, hw = int(m.group(1)), int(m.group(2))
