@@ -17,7 +17,23 @@ import torch
 from . import _hip
 from . import bnlink as _bnlink
 
+import collections
 import contextlib
+
+# Layers of a GPU model that did NOT take one of this package's kernels (a shape off the tables, a switch set to 0)
+# are counted here per (operator, per-sample shape); SGMCMC_STRICT=1 turns such a library dispatch into an error --
+# for production runs of the BASELINE configurations, whose steps contain no library compute kernel.
+STRICT = os.environ.get("SGMCMC_STRICT", "0") == "1"
+LIBRARY_CALLS = collections.Counter()
+
+
+def library_path(op, x):
+    if x.is_cuda and torch.is_grad_enabled():      # (gradient evaluations only: evaluation passes are not the hot path)
+        LIBRARY_CALLS[(op, tuple(x.shape[1:]))] += 1
+        if STRICT:
+            raise RuntimeError(f"SGMCMC_STRICT=1: {op} on a per-sample shape {tuple(x.shape[1:])} has no kernel in "
+                               "bnn_priors_amd and would run on the library path (MIOpen / rocBLAS / ATen)")
+
 
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"

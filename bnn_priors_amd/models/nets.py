@@ -50,6 +50,7 @@ class Linear(_PriorBacked):
         w, b = self.weight, self.bias
         if _pool.linear_supported(x, w, b):        # a head with a few outputs: one launch each way (pool.linear)
             return _pool.linear(x, w, b)
+        _conv.library_path("linear", x)
         return nn.functional.linear(x, w, b)
 
 
@@ -68,6 +69,7 @@ class Conv2d(_PriorBacked):
             return _conv.conv3x3(x, w, want_stats)
         if _conv.stem_supported(x, w, b, *self.conv_args):
             return _conv.conv_stem(x, w, want_stats)
+        _conv.library_path("conv2d", x)
         y = nn.functional.conv2d(x, w, b, *self.conv_args)
         return (y, None) if want_stats else y
 
@@ -212,6 +214,8 @@ class _BatchNorm2d(nn.BatchNorm2d):
         if self.track_running_stats and _bn.supported(x, self.weight, self.bias, self.training, self.momentum):
             return _bn.bn_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                 self.momentum, self.eps, residual, relu, stats)
+        if self.training:
+            _conv.library_path("batch_norm", x)
         if self.momentum is None or not self.track_running_stats:
             y = super().forward(x)
         else:

@@ -434,3 +434,36 @@ def test_convnet_has_no_library_convolution_left(monkeypatch):
     ref = net.net(x.cuda())
     assert called
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,xshape", [("googleresnet", (3, 32, 32)), ("classificationconvnet", (784,))])
+def test_baseline_conv_models_take_no_library_path_in_a_gradient_evaluation(name, xshape):
+    """configs[2] and [3]: a forward + backward of the model dispatches nothing to MIOpen / rocBLAS / ATen compute
+    (conv.LIBRARY_CALLS stays empty; SGMCMC_STRICT=1 would raise instead of counting); an off-table shape is counted."""
+    from bnn_priors_amd import models
+    torch.manual_seed(0)
+    x = torch.randn((8,) + xshape).cuda()
+    y = (torch.arange(8) % 10).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), name, width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()     # (10 classes)
+    net.train()
+    conv.LIBRARY_CALLS.clear()
+    F.cross_entropy(net.net(x), y).backward()
+    assert not conv.LIBRARY_CALLS, dict(conv.LIBRARY_CALLS)
+    torch.cuda.synchronize()
+    # what an off-table layer would do: counted (and refused under SGMCMC_STRICT=1) -- without running the library here
+    odd = torch.empty(4, 3, 24, 24, device="cuda")
+    conv.library_path("conv2d", odd)
+    assert conv.LIBRARY_CALLS == {("conv2d", (3, 24, 24)): 1}
+    conv.LIBRARY_CALLS.clear()
+    old = conv.STRICT
+    conv.STRICT = True
+    try:
+        with pytest.raises(RuntimeError, match="SGMCMC_STRICT"):
+            conv.library_path("conv2d", odd)
+        with torch.no_grad():
+            conv.library_path("conv2d", odd)            # evaluation passes are not policed
+    finally:
+        conv.STRICT = old
+        conv.LIBRARY_CALLS.clear()

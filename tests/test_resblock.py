@@ -152,7 +152,7 @@ def test_batchnorm_backward_sums_ride_in_the_upstream_convolution_gradient(monke
     torch.manual_seed(0)
     x = torch.randn(16, 3, 32, 32).cuda()
     y = torch.randint(0, 10, (16,)).cuda()
-    net = models.get_model(x.cpu()[:2], y.cpu()[:2], "googleresnet", width=50, depth=3, weight_prior="gaussian",
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
                            weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
     models.he_initialize(net)
     net.train()
