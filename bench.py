@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
     ap.add_argument("--chain-sweep", default="1,2,4,8",
                     help="densenet only: aggregate steps/s of K chains sharing ONE GPU's launches (MultiChainDense); '' = skip")
+    ap.add_argument("--stream-chains", default="",
+                    help="googleresnet / convnet: aggregate steps/s of K chains on K HIP streams of ONE GPU, e.g. '1,2,3' "
+                         "(after the timed region; off by default)")
     return ap.parse_args()
 
 
@@ -278,6 +281,62 @@ def flat_arena_point(log2n, device, iters=20):
                 achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                 traffic=None, algorithmic_bytes_per_launch=BYTES_PER_PARAM * n, elements=n,
                 avg_kernel_ms=round(avg_ms, 4), min_kernel_ms=round(min(times), 4), launches=len(times))
+
+
+# ------------------------------------------------------------------ several chains per GPU (captured-graph nets)
+def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
+    """K independent chains of a captured-graph workload (googleresnet, convnet) on ONE GPU, each on its own HIP
+    stream: the chains' dependent launch chains interleave on the GPU (a step is ~90 dependent kernels, each of which
+    leaves the GPU partly idle at its boundaries).  Aggregate leapfrog steps/s = K * steps / time, per K."""
+    from bnn_priors_amd.inference_reject import runner_class
+    from bnn_priors_amd.storage import MemoryMetrics
+    name, xshape, N, prior = WORKLOADS[args.workload]
+    pool = PoolSource(args.workload, N, device, 4321 + rank)           # read-only: shared by the chains
+    batches = [b for b in pool if len(b[0]) == 128]
+    runners, streams, steps_of = [], [], []
+    for c in range(max(ks)):
+        st = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):
+            model = make_model(args.workload, device, args.weight_prior)
+            loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
+            empty = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
+            r = runner_class("VerletSGLDReject")(
+                model=model, dataloader=loader, dataloader_test=empty, epochs_per_cycle=50, warmup_epochs=45,
+                sample_epochs=5, learning_rate=0.01, skip=1, metrics_skip=args.metrics_skip, temperature=1.0,
+                momentum=0.994, sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
+                model_saver=None, reject_samples=True, seed=1234, chain_id=8 * rank + c)
+            r._batch_source = pool
+            r.use_graph = True
+            steps_of.append(r.begin())
+        runners.append(r)
+        streams.append(st)
+    torch.cuda.synchronize(device)
+    out = {}
+    for K in sorted(ks):
+        def run(n):
+            for _ in range(n):
+                for c in range(K):
+                    steps_of[c] += 1
+                    x, y = batches[(steps_of[c] + 13 * c) % len(batches)]
+                    with torch.cuda.stream(streams[c]):
+                        runners[c].leapfrog(steps_of[c], x, y, last_of_epoch=False)
+        run(warmup)
+        for c in range(K):
+            with torch.cuda.stream(streams[c]):
+                runners[c]._drain_rows()
+        torch.cuda.synchronize(device)
+        ts = time.perf_counter()
+        run(steps)
+        for c in range(K):
+            with torch.cuda.stream(streams[c]):
+                runners[c]._drain_rows()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - ts
+        for c in range(K):
+            runners[c]._check_finite()
+        out[str(K)] = {"aggregate_steps_per_s": round(K * steps / dt, 1), "per_chain_steps_per_s": round(steps / dt, 1),
+                       "us_per_lockstep": round(dt / steps * 1e6, 2)}
+    return out
 
 
 # ------------------------------------------------------------------ several chains per GPU (the small nets)
@@ -639,6 +698,9 @@ def main():
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
         if args.workload == "densenet" and args.chain_sweep and args.inference == "VerletSGLDReject":
             out["chains_per_gpu"] = chains_per_gpu_sweep(args, device, rank, [int(k) for k in args.chain_sweep.split(",")])
+        if args.workload != "densenet" and args.stream_chains and args.inference == "VerletSGLDReject":
+            out["chains_per_gpu"] = dict(chains_per_gpu_streams(args, device, rank, [int(k) for k in args.stream_chains.split(",")]),
+                                         method="K runners, each with its own captured step on its own HIP stream")
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]
