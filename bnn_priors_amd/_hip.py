@@ -220,6 +220,8 @@ EXPORTS = {
                                + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
                               + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
+                                + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_sum_slices": (ctypes.c_int, [ctypes.c_int] * 3),
     "sgmcmc_conv_down_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ConvBwdEpilogue)]
                                 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),

@@ -194,10 +194,14 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None):
         E.s_y, E.s_out, E.s_mean, E.s_invstd = y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(), saved_bn[1].data_ptr()
         E.s_partial = partial.data_ptr()
     slabs = ctypes.c_int(0)
-    err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E), 0,
-                                    part.data_ptr(), n, c, hw, ctypes.byref(slabs), s)
-    if err:
-        _hip.check(err, "sgmcmc_conv3x3_bwd_ex")
+    if _conv.SIDE_STREAM and _conv._may_defer(w):
+        # the weight-gradient slabs leave the critical path: side stream, joined before the pass's slab reduction
+        _conv.split_backward(lib, x, w, dy, dx, E, part, slabs)
+    else:
+        err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E), 0,
+                                        part.data_ptr(), n, c, hw, ctypes.byref(slabs), s)
+        if err:
+            _hip.check(err, "sgmcmc_conv3x3_bwd_ex")
     return dx, _reduce_or_defer(lib, w, part, slabs.value, s), partial, n_partials
 
 

@@ -415,6 +415,13 @@ typedef struct {
 int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float* dx,
                           const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
                           int hw, int* deferred_slabs, void* stream);
+/* One half of sgmcmc_conv3x3_bwd_ex on its own: which = 1 the data gradient (dx, with the epilogues of `epi`, which may
+ * be NULL), which = 2 the weight-gradient slabs (always deferred: *deferred_slabs receives their number).  The halves are
+ * independent given dy, so a caller can run the weight gradient on a second stream, off the critical path of the
+ * backward pass; same workgroups, same bits as the merged launch. */
+int sgmcmc_conv3x3_bwd_part(const float* x, const float* w, const float* dy, float* dx,
+                            const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
+                            int which, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;

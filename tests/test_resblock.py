@@ -184,3 +184,30 @@ def test_batchnorm_backward_sums_ride_in_the_upstream_convolution_gradient(monke
     assert bnlink.sums_of(t) is not None
     t.add_(1.0)
     assert bnlink.sums_of(t) is None
+
+
+def test_weight_gradients_on_a_side_stream_have_the_same_bits(monkeypatch):
+    """conv.SIDE_STREAM (off by default: measured slower inside a replayed graph): the weight-gradient half of every
+    trunk convolution's backward on a second stream, joined before the pass's slab reduction -- same workgroups, so
+    every gradient is bit-identical to the merged launches'."""
+    from bnn_priors_amd import conv, models
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, 32, 32).cuda()
+    y = (torch.arange(8) % 10).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    net.train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    outs = []
+    for side in (False, True):
+        monkeypatch.setattr(conv, "SIDE_STREAM", side)
+        net.load_state_dict(state)
+        for p in net.parameters():
+            p.grad = None
+        with conv.deferring():
+            torch.nn.functional.cross_entropy(net.net(x), y).backward()
+        torch.cuda.synchronize()
+        assert not conv._pending and conv._side["forked"] is None and not conv._side["keep"]
+        outs.append([p.grad.clone() for p in net.parameters()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
