@@ -24,7 +24,6 @@ gradient tensors whenever control moves between paths.
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from . import conv as _conv
 from . import pool as _pool

@@ -16,7 +16,6 @@ ATen launches and two validation syncs per prior tensor per step).  Here
 Nothing here synchronises with the host; callers ``.item()`` what they log.
 """
 import torch
-import torch.nn.functional as F
 
 from . import conv as _conv
 from . import pool as _pool
