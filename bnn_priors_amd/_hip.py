@@ -208,6 +208,7 @@ EXPORTS = {
     "sgmcmc_bias_relu_pool_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_bias_relu_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "sgmcmc_pool_linear_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 11 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "sgmcmc_linear_row_groups": (ctypes.c_int, [ctypes.c_int]),

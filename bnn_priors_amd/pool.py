@@ -8,6 +8,7 @@ import os
 import torch
 
 from . import _hip
+from . import bnlink as _bnlink
 from . import conv as _conv
 
 ENABLED = os.environ.get("SGMCMC_POOL", "1") != "0"
@@ -101,7 +102,7 @@ def _reduce_rows(slabs, out, defer):
 
 class _PoolLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, bias):
+    def forward(ctx, h, weight, bias, src_y=None, src_saved=None):
         _conv._note_use(*((weight,) if bias is None else (weight, bias)))
         h, weight = h.contiguous(), weight.contiguous()
         n, c, plane, k = h.shape[0], h.shape[1], h.shape[2] * h.shape[3], weight.shape[0]
@@ -111,14 +112,14 @@ class _PoolLinear(torch.autograd.Function):
                                                 pooled.data_ptr(), logits.data_ptr(), n, c, plane, k, _conv._stream())
         if err:
             _hip.check(err, "sgmcmc_pool_linear_fwd")
-        ctx.save_for_backward(pooled, weight, bias)
+        ctx.save_for_backward(pooled, weight, bias, src_y, src_saved, h if src_y is not None else None)
         ctx.h_shape = tuple(h.shape)
         return logits
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dlogits):
-        pooled, weight, bias = ctx.saved_tensors
+        pooled, weight, bias, src_y, src_saved, h = ctx.saved_tensors
         dlogits = dlogits.contiguous()
         n, c, hh, ww = ctx.h_shape
         k = weight.shape[0]
@@ -127,9 +128,17 @@ class _PoolLinear(torch.autograd.Function):
         want_w, want_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         sw = torch.empty((n, k * c), dtype=torch.float32, device=dev) if want_w else None
         sb = torch.empty((n, k), dtype=torch.float32, device=dev) if want_b else None
-        err = _hip.lib().sgmcmc_pool_linear_bwd(dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
-                                                0 if sw is None else sw.data_ptr(), 0 if sb is None else sb.data_ptr(),
-                                                n, c, hh * ww, k, _conv._stream())
+        if src_y is not None:      # h came out of a BatchNorm + ReLU: its backward sums ride in this launch (bnlink)
+            partial = torch.empty((c, n, 2), dtype=torch.float64, device=dev)
+            err = _hip.lib().sgmcmc_pool_linear_bwd_sums(
+                dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
+                0 if sw is None else sw.data_ptr(), 0 if sb is None else sb.data_ptr(), src_y.data_ptr(), h.data_ptr(),
+                src_saved[0].data_ptr(), src_saved[1].data_ptr(), partial.data_ptr(), n, c, hh * ww, k, _conv._stream())
+            _bnlink.tag_gradient(dh, partial, n)
+        else:
+            err = _hip.lib().sgmcmc_pool_linear_bwd(dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
+                                                    0 if sw is None else sw.data_ptr(), 0 if sb is None else sb.data_ptr(),
+                                                    n, c, hh * ww, k, _conv._stream())
         if err:
             _hip.check(err, "sgmcmc_pool_linear_bwd")
         dw = db = None
@@ -137,12 +146,15 @@ class _PoolLinear(torch.autograd.Function):
             dw = _reduce_rows(sw, torch.empty_like(weight), _conv._may_defer(weight))
         if want_b:
             db = _reduce_rows(sb, torch.empty_like(bias), _conv._may_defer(bias))
-        return dh, dw, db
+        return dh, dw, db, None, None
 
 
 def pool_linear(h, weight, bias=None):
     "linear(h.mean(dim=(2, 3)), weight, bias) for NCHW float32 h with <= 64 channels and <= 16 outputs"
-    return _PoolLinear.apply(h, weight, bias)
+    src_y, src_saved = (None, None)
+    if h.requires_grad and h.shape[2] * h.shape[3] == 64:
+        src_y, src_saved = _bnlink.source_of(h)
+    return _PoolLinear.apply(h, weight, bias, src_y, src_saved)
 
 
 # ------------------------------------------------------------------ narrow linear layer

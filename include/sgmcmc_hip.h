@@ -534,6 +534,13 @@ int sgmcmc_pool_linear_fwd(const float* h, const float* weight, const float* bia
 int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const float* weight, float* dh,
                            float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
                            void* stream);
+/* ... when h is the output of a BatchNorm + ReLU (bn_y its input, bn_out = h, saved mean / invstd) on 8x8 maps
+ * (plane == 64): the launch also leaves that BatchNorm's backward sums, partial[(c * n + image) * 2 + {0,1}] doubles
+ * (n slices per channel) for sgmcmc_bn_bwd_dx -- the last BatchNorm of models/google_resnet.py:103-110's trunk. */
+int sgmcmc_pool_linear_bwd_sums(const float* dlogits, const float* pooled, const float* weight, float* dh,
+                                float* slab_w, float* slab_b, const float* bn_y, const float* bn_out,
+                                const float* bn_mean, const float* bn_invstd, double* partial, int n, int channels,
+                                int plane, int classes, void* stream);
 
 /* ---- BatchNorm backward folded into the convolution's gradient launch (csrc/conv_fused_hip.inc) ----------
  * For a "conv3x3 -> BatchNorm(train) -> [+ shortcut] -> ReLU" pair of the ResNet trunk (google_resnet.py:34-43,
