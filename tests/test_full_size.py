@@ -1,0 +1,86 @@
+"""Size-independent properties at BASELINE.json's full sizes (googleresnet, batch 128, 272,474 parameters in 65
+tensors) -- where no golden from the reference exists because the oracle would not finish in seconds:
+
+* reproducibility: the whole captured path (on-device augmentation, convolution / BatchNorm kernels with their
+  epilogue hand-overs, deferred bookkeeping, M-H points) gives the same bits twice from the same seeds;
+* a rejected proposal restores parameters and momentum to the saved state exactly (verlet_sgld.py:62-69)."""
+import numpy as np
+import pytest
+import torch
+
+import runner_cases as RC
+from bnn_priors_amd import inference_reject, models
+from bnn_priors_amd.storage import MemoryMetrics
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_once():
+    from bnn_priors_amd.augment import AugmentedTensorDataset, RandomCropFlip
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    n = 1024                                                # 8 minibatches of 128 per epoch
+    x = torch.randn((n, 3, 32, 32), generator=g).to(dev)
+    y = torch.randint(0, 10, (n,), generator=g).to(dev)
+    ds = AugmentedTensorDataset(x, y, RandomCropFlip(pad=4, flip=True, seed=99, stream=0))
+    train = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:256], y[:256]), batch_size=128)
+    model = RC.make_net(models, x[:2].cpu(), torch.tensor([0, 9]), device=dev, cfg=dict(model="googleresnet"))
+    metrics = MemoryMetrics()
+    torch.manual_seed(RC.SEED)
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, learning_rate=0.002, temperature=1.0, momentum=0.98,
+        reject_samples=True, metrics_saver=metrics, model_saver=None, seed=RC.SEED, chain_id=0,
+        cycle_seed=RC.CYCLE_SEED, use_graph=True, **RC.RUN_KW)
+    runner.run()
+    assert runner._graphed not in (None, False)             # the captured path ran
+    return RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}
+
+
+def test_googleresnet_batch128_run_is_bitwise_reproducible():
+    (s0, p0), (s1, p1) = _run_once(), _run_once()
+    assert sorted(s0) == sorted(s1) and sorted(p0) == sorted(p1)
+    for k in s0:
+        if k == "timestamps":
+            continue
+        assert np.array_equal(s0[k][0], s1[k][0]), k
+        assert np.array_equal(s0[k][1], s1[k][1]), k
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    assert np.isfinite(s0["potential"][1]).all() and len(s0["acceptance/rejected"][1]) > 0
+
+
+@pytest.mark.parametrize("kind", ["verlet", "hmc"])
+def test_rejected_proposal_restores_the_saved_state_exactly_at_googleresnet_size(kind):
+    from bnn_priors_amd import mcmc
+    net = models.get_model(torch.zeros(2, 3, 32, 32), torch.tensor([0, 9]), "googleresnet", width=50, depth=3,
+                           weight_prior="gaussian", weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
+    g = torch.Generator().manual_seed(3)
+    params = [torch.nn.Parameter(torch.randn(p.shape, generator=g).cuda()) for p in net.parameters()]
+    assert sum(p.numel() for p in params) == 272474
+    if kind == "hmc":
+        opt = mcmc.HMC(params, lr=1e-3, num_data=50000, seed=5, chain_id=1)
+    else:
+        opt = mcmc.VerletSGLD(params, lr=1e-3, num_data=50000, momentum=0.994, temperature=1.0, seed=5, chain_id=1)
+
+    def grads():
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+    opt.sample_momentum()
+    grads()
+    theta0 = [p.detach().clone() for p in params]
+    mom0 = [opt.state[p]['momentum_buffer'].clone() for p in params]
+    opt.initial_step(save_state=True)
+    for _ in range(5):
+        grads()
+        opt.step()
+    grads()
+    opt.final_step()
+    assert any(not torch.equal(p.detach(), t) for p, t in zip(params, theta0))
+    rejected, _ = opt.maybe_reject(float("inf"))            # log u > -inf: always rejected
+    assert rejected
+    for p, t, m in zip(params, theta0, mom0):
+        assert torch.equal(p.detach(), t)
+        assert torch.equal(opt.state[p]['momentum_buffer'], m)
+    accepted, _ = opt.maybe_reject(float("-inf"))           # ... and never for -inf
+    assert not accepted
