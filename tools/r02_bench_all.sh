@@ -16,4 +16,4 @@ for f in ("bench_googleresnet_driver_args","bench_convnet","bench_densenet","ben
     except Exception as e:
         print(f, "FAILED", e)
 PY
-tail -3 $OUT/*.err
+tail -n 3 $OUT/*.err
