@@ -191,6 +191,10 @@ EXPORTS = {
     "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
                             + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_bn_train_fwd_log": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double] + [ctypes.c_int] * 4
+                                + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_bn_running_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6),
     "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
                            + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),

@@ -8,6 +8,7 @@ residual.  Two launches forward (one when the producing convolution hands over t
 backward, deterministic statistics (no atomics).
 Reference: the BatchNorm layers of bnn_priors/models/google_resnet.py:34-43, 77-90.
 """
+import contextlib
 import ctypes
 import os
 
@@ -29,6 +30,66 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+# ---- running statistics logged instead of updated ---------------------------------------------------------------
+# Inside ``with logging_running_stats(slots):`` (slots: id(running_mean tensor) -> float64 [C, 2] device tensor) a
+# training-mode forward leaves its batch mean / unbiased variance in the layer's slot and does NOT touch the running
+# statistics; ``replay_running_stats`` advances them later by a sequence of logged batches, in order (the same bits
+# as forwards in that order).  Used by the exact full-data pass when its minibatches run on several streams at once
+# (graphed.ConcurrentAccumulate).  A BatchNorm that cannot log (library path) raises LogModeUnsupported.
+_log = {"slots": None}
+
+
+class LogModeUnsupported(RuntimeError):
+    pass
+
+
+@contextlib.contextmanager
+def logging_running_stats(slots):
+    old = _log["slots"]
+    _log["slots"] = slots
+    try:
+        yield
+    finally:
+        _log["slots"] = old
+
+
+def log_active():
+    return _log["slots"] is not None
+
+
+def log_slot(running_mean):
+    "the slot of the BatchNorm that owns ``running_mean`` while logging is active, else None"
+    slots = _log["slots"]
+    if slots is None or running_mean is None:
+        return None
+    slot = slots.get(id(running_mean))
+    if slot is None:
+        raise LogModeUnsupported("a BatchNorm layer outside the logged set ran in log mode")
+    return slot
+
+
+def train_fwd(lib, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, n, c, plane, y, saved,
+              scratch, stats_in, stats_slices, stream):
+    "sgmcmc_bn_train_fwd, or its logging variant while ``logging_running_stats`` is active (all arguments tensors / None)"
+    slot = log_slot(running_mean)
+    if slot is None:
+        return lib.sgmcmc_bn_train_fwd(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(),
+                                       _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu),
+                                       n, c, plane, y.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(),
+                                       _ptr(scratch), _ptr(stats_in), stats_slices, stream)
+    return lib.sgmcmc_bn_train_fwd_log(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(), slot.data_ptr(),
+                                       float(eps), int(relu), n, c, plane, y.data_ptr(), saved[0].data_ptr(),
+                                       saved[1].data_ptr(), _ptr(scratch), _ptr(stats_in), stats_slices, stream)
+
+
+def replay_running_stats(log, entry_stride, n_entries, momentum, running_mean, running_var, stream):
+    "running_mean / running_var advanced by n_entries logged batches (log: data pointer of the first entry's slot)"
+    err = _hip.lib().sgmcmc_bn_running_replay(log, entry_stride, n_entries, float(momentum), running_mean.data_ptr(),
+                                              running_var.data_ptr(), running_mean.numel(), stream)
+    if err:
+        _hip.check(err, "sgmcmc_bn_running_replay")
+
+
 class _BNTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats_in,
@@ -47,12 +108,9 @@ class _BNTrain(torch.autograd.Function):
         elif stats_in.dtype != torch.float64 or stats_in.dim() != 3 or stats_in.shape[0] != c \
                 or stats_in.shape[2] != 2 or not stats_in.is_contiguous():
             raise ValueError("stats must be a contiguous float64 [channels][slices][2] tensor")
-        err = lib.sgmcmc_bn_train_fwd(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(),
-                                      _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-                                      int(relu), n, c, plane, y.data_ptr(), stats[0].data_ptr(),
-                                      stats[1].data_ptr(), _ptr(scratch), _ptr(stats_in),
-                                      0 if stats_in is None else stats_in.shape[1],
-                                      torch.cuda.current_stream().cuda_stream)
+        err = train_fwd(lib, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, n, c, plane, y,
+                        stats, scratch, stats_in, 0 if stats_in is None else stats_in.shape[1],
+                        torch.cuda.current_stream().cuda_stream)
         if err:
             _hip.check(err, "sgmcmc_bn_train_fwd")
         ctx.save_for_backward(x, weight, y if relu else None, stats, res_y, res_saved)

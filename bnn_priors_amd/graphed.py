@@ -21,10 +21,13 @@ estimates -- into one buffer that is read back with a single copy.  M-H points a
 batches keep using the eager path; ``p.grad`` is re-bound to the replayed graph's static
 gradient tensors whenever control moves between paths.
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 
+from . import bn as _bn
 from . import conv as _conv
 from . import pool as _pool
 
@@ -283,9 +286,13 @@ class GraphedAccumulate:
     BatchNorm nets update their running statistics on every replay exactly as the eager pass does;
     the capture's warm-up runs are undone from a snapshot of the model's buffers."""
 
-    def __init__(self, potential, optimizer, x_example, y_example, warmup=2):
+    def __init__(self, potential, optimizer, x_example, y_example, warmup=2, log_slots=None):
+        """``log_slots`` (id(running_mean) -> float64 [C, 2] tensor): the BatchNorm layers leave their batch statistics
+        there instead of advancing their running statistics (bn.logging_running_stats) -- for a lane of
+        ``ConcurrentAccumulate``, which advances them afterwards in batch order."""
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.model = potential.model
+        self.log_slots = log_slots
         dev = self.eng.device
         self.x = torch.empty_like(x_example, device=dev)
         self.y = torch.empty_like(y_example, device=dev)
@@ -311,6 +318,9 @@ class GraphedAccumulate:
                 v.copy_(buffers[k])
         torch.cuda.synchronize(dev)
 
+    def _logging(self):
+        return _bn.logging_running_stats(self.log_slots) if self.log_slots is not None else contextlib.nullcontext()
+
     def _accumulate(self, x, y):
         # every batch's gradient lands in FRESH tensors (autograd adopts them: no per-tensor `grad += ...`
         # launches, and the convolution slabs take their one deferred reduction), then ONE multi-tensor add
@@ -318,7 +328,7 @@ class GraphedAccumulate:
         params = self.eng.params
         for p in params:
             p.grad = None
-        with _conv.deferring():
+        with self._logging(), _conv.deferring():
             this = _pool.cross_entropy_backward(self.pot._logits(x), y, reduction="sum", divide_by=self.pot.N)
         got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none
         torch._foreach_add_([a for a, _ in got], [g for _, g in got])
@@ -347,3 +357,116 @@ class GraphedAccumulate:
     def add_eager(self, x, y):
         "same accumulation without the graph (any batch shape)"
         self._accumulate(x, y)
+
+
+# ------------------------------------------------------------------ the exact pass on several streams
+EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "2"))
+
+
+class ConcurrentAccumulate:
+    """The exact full-data gradient with its minibatches evaluated on ``lanes`` HIP streams at once: every lane is a
+    ``GraphedAccumulate`` with its own captured body, static inputs and accumulators; minibatch j goes to lane
+    j mod lanes.  A gradient evaluation is a chain of ~90 dependent launches that leaves the GPU partly idle at
+    every boundary; two independent chains interleave (1.36x one chain's throughput for googleresnet, 1.42x for the
+    convolutional classifier).  The minibatches of this pass are independent given the parameters
+    (inference_reject.py:18-33) -- except that training-mode BatchNorm advances its running statistics batch by batch:
+    the lanes therefore LOG every layer's batch mean / unbiased variance (``bn.logging_running_stats``) and the
+    running statistics are advanced afterwards from the log in minibatch order, with the arithmetic of the in-kernel
+    update (same bits as the sequential pass); ``num_batches_tracked`` is advanced by the number of minibatches.
+    The gradient is the sum of the lanes' accumulators (a fixed order: reproducible; the sequential pass adds the
+    minibatches in another order, so the two agree to rounding, not bit for bit).  Off-shape minibatches (the ragged
+    last one) are evaluated eagerly, in order, after the lanes have been joined."""
+
+    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=512):
+        self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
+        self.model = potential.model
+        dev = self.dev = self.eng.device
+        self.bn_layers = [m for m in self.model.modules()
+                          if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_mean is not None]
+        if any(m.momentum is None for m in self.bn_layers):
+            raise _bn.LogModeUnsupported("cumulative-average BatchNorm")
+        self.cmax = max([m.num_features for m in self.bn_layers], default=1)
+        self.n_bn = len(self.bn_layers)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self.lanes, self.log_cur = [], []
+        main = torch.cuda.current_stream(dev)
+        for s in self.streams:
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                cur = torch.zeros((max(self.n_bn, 1), self.cmax, 2), dtype=torch.float64, device=dev)
+                slots = {id(m.running_mean): cur[i, :m.num_features] for i, m in enumerate(self.bn_layers)}
+                self.lanes.append(GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots))
+                self.log_cur.append(cur)
+            main.wait_stream(s)
+        self.log_all = torch.zeros((capacity,) + tuple(self.log_cur[0].shape), dtype=torch.float64, device=dev)
+        self.loss = self.lanes[0].loss
+        self.count = self.logged_from = 0
+
+    def matches(self, x, y):
+        return self.lanes[0].matches(x, y)
+
+    def begin(self):
+        main = torch.cuda.current_stream(self.dev)
+        for s, lane in zip(self.streams, self.lanes):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                lane.begin()
+        self.count = self.logged_from = 0
+
+    def run(self, batches):
+        "every minibatch of ``batches`` (an iterable of (x, y)), fetched under the stream of the lane that evaluates it"
+        it = iter(batches)
+        while True:
+            if self.count - self.logged_from >= self.log_all.shape[0]:      # the log is full: advance and start over
+                self._join_and_replay()
+            k = self.count % len(self.lanes)
+            with torch.cuda.stream(self.streams[k]):
+                try:
+                    x, y = next(it)
+                except StopIteration:
+                    break
+                if self.matches(x, y):
+                    self.lanes[k].add(x, y)
+                    if self.n_bn:
+                        self.log_all[self.count - self.logged_from].copy_(self.log_cur[k], non_blocking=True)
+                    self.count += 1
+                    continue
+            # an off-shape minibatch: in order, on the main stream, with the ordinary running-statistics update
+            self._join_and_replay()
+            x, y = x.to(self.dev), y.to(self.dev)
+            torch.cuda.current_stream(self.dev).wait_stream(self.streams[k])       # (x was produced there)
+            self.lanes[0].log_slots, keep = None, self.lanes[0].log_slots
+            try:
+                self.lanes[0].add_eager(x, y)
+            finally:
+                self.lanes[0].log_slots = keep
+            for s in self.streams:
+                s.wait_stream(torch.cuda.current_stream(self.dev))
+        self._join_and_replay()
+
+    def _join_and_replay(self):
+        "lanes joined into the current stream; the running statistics advanced by the minibatches logged since the last join"
+        main = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            main.wait_stream(s)
+        n = self.count - self.logged_from
+        if n and self.n_bn:
+            stride = self.log_all.stride(0)
+            for i, m in enumerate(self.bn_layers):
+                _bn.replay_running_stats(self.log_all[0, i].data_ptr(), stride, n, m.momentum, m.running_mean,
+                                         m.running_var, main.cuda_stream)
+            with torch.no_grad():
+                torch._foreach_add_([m.num_batches_tracked for m in self.bn_layers], n)
+        self.logged_from = self.count
+        for s in self.streams:
+            s.wait_stream(main)            # the log may be overwritten / the statistics read from here on
+
+    def finish(self):
+        "the lanes' accumulators summed into lane 0's, which become the parameters' gradient"
+        main = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            main.wait_stream(s)
+        for lane in self.lanes[1:]:
+            torch._foreach_add_(self.lanes[0].grads, lane.grads)
+            self.lanes[0].loss += lane.loss
+        self.lanes[0].finish()

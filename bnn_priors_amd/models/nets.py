@@ -215,6 +215,8 @@ class _BatchNorm2d(nn.BatchNorm2d):
             return _bn.bn_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                 self.momentum, self.eps, residual, relu, stats)
         if self.training:
+            if _bn.log_active():
+                raise _bn.LogModeUnsupported("a BatchNorm layer on the library path cannot log its batch statistics")
             _conv.library_path("batch_norm", x)
         if self.momentum is None or not self.track_running_stats:
             y = super().forward(x)
@@ -258,7 +260,7 @@ class _BNTrunk(nn.Sequential):
                 out, i = _pool.pool_linear(out, lin.weight, lin.bias), i + 3
             else:
                 out, i = m(out), i + 1
-        if self.training:
+        if self.training and not _bn.log_active():       # (log mode: the caller advances the counters afterwards)
             counters = self.__dict__.get("_bn_counters")
             if counters is None or any(c is not m.num_batches_tracked for c, m in counters):
                 counters = [(m.num_batches_tracked, m) for m in self.modules()

@@ -15,6 +15,8 @@ ATen launches and two validation syncs per prior tensor per step).  Here
 
 Nothing here synchronises with the host; callers ``.item()`` what they log.
 """
+import itertools
+
 import torch
 
 from . import conv as _conv
@@ -74,6 +76,18 @@ class Potential:
     # ------------------------------------------------------------------ full-data gradient
     graph_exact = False     # set by the runner (``use_graph``): capture the exact pass's batch body
 
+    def _make_exact_accumulator(self, x, y):
+        """graph-captured accumulation: L launches, no read-back (graphed.GraphedAccumulate) -- for the launch-bound
+        convolutional nets on EXACT_LANES streams at once (graphed.ConcurrentAccumulate)"""
+        from . import bn as _bn, graphed
+        from .models import nets
+        if graphed.EXACT_LANES > 1 and any(isinstance(m, nets.Conv2d) for m in self.model.modules()):
+            try:
+                return graphed.ConcurrentAccumulate(self, self.opt, x, y, lanes=graphed.EXACT_LANES)
+            except _bn.LogModeUnsupported:
+                pass
+        return graphed.GraphedAccumulate(self, self.opt, x, y)
+
     def _may_graph_exact(self, batches):
         return (self.graph_exact and not self.leftover and self.opt.engine.device.type == "cuda"
                 and len(batches) >= 4)      # fewer batches are not worth a capture
@@ -97,12 +111,17 @@ class Potential:
         loss = torch.zeros((), dtype=torch.float64, device=self.opt.engine.device)
         if acc is not None:
             acc.begin()
-        for x, y in batches:        # (never peeked at: iterating the loader draws from its RNG)
-            if may_graph and acc is None:
-                # graph-captured accumulation (graphed.GraphedAccumulate): L launches, no read-back
-                from .graphed import GraphedAccumulate
-                acc = self._exact_acc = GraphedAccumulate(self, self.opt, x, y)
+        batches = iter(batches)      # (never peeked at beyond what is consumed: iterating the loader draws from its RNG)
+        if may_graph and acc is None:
+            first = next(batches, None)
+            if first is not None:
+                acc = self._exact_acc = self._make_exact_accumulator(*first)
                 acc.begin()
+                batches = itertools.chain([first], batches)
+        if acc is not None and hasattr(acc, "run"):
+            acc.run(batches)         # minibatches on several streams at once (graphed.ConcurrentAccumulate)
+            batches = ()
+        for x, y in batches:
             if acc is not None:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:

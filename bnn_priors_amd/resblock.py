@@ -28,6 +28,7 @@ import os
 import torch
 
 from . import _hip
+from . import bn as _bn
 from . import bnlink as _bnlink
 from . import conv as _conv
 
@@ -82,9 +83,7 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
     err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s)
     if err:
         _hip.check(err, "sgmcmc_conv3x3")
-    err = lib.sgmcmc_bn_train_fwd(y.data_ptr(), _p(residual), g.data_ptr(), b.data_ptr(), _p(rm), _p(rv), float(mom),
-                                  float(eps), 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(),
-                                  saved[1].data_ptr(), 0, stats.data_ptr(), slices, s)
+    err = _bn.train_fwd(lib, y, residual, g, b, rm, rv, mom, eps, 1, n, c, hw * hw, out, saved, None, stats, slices, s)
     if err:
         _hip.check(err, "sgmcmc_bn_train_fwd")
     return y, out, saved

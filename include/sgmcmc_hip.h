@@ -493,6 +493,18 @@ int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamm
                         float* running_mean, float* running_var, double momentum, double eps, int relu,
                         int n, int channels, int plane, float* y, float* save_mean, float* save_invstd,
                         double* scratch, const double* stats_in, int stats_slices, void* stream);
+/* The same forward with the running statistics left ALONE: the batch mean and unbiased variance of every channel go to
+ * stat_log[2 c + {0,1}] (doubles) instead, and sgmcmc_bn_running_replay advances running_mean / running_var by a
+ * sequence of such entries (log + j * entry_stride doubles, j = 0 .. n_entries - 1) in order -- the same bits as
+ * n_entries forwards in that order.  For gradient passes whose minibatches are evaluated concurrently on several
+ * streams (the exact full-data pass, inference_reject.py:18-33) while nn.BatchNorm2d's running statistics must still
+ * advance batch by batch. */
+int sgmcmc_bn_train_fwd_log(const float* x, const float* residual, const float* gamma, const float* beta,
+                            double* stat_log, double eps, int relu, int n, int channels, int plane, float* y,
+                            float* save_mean, float* save_invstd, double* scratch, const double* stats_in,
+                            int stats_slices, void* stream);
+int sgmcmc_bn_running_replay(const double* log, int64_t entry_stride, int n_entries, double momentum,
+                             float* running_mean, float* running_var, int channels, void* stream);
 int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const float* gamma,
                         const float* save_mean, const float* save_invstd, int relu, int n, int channels,
                         int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,

@@ -84,3 +84,56 @@ def test_rejected_proposal_restores_the_saved_state_exactly_at_googleresnet_size
         assert torch.equal(opt.state[p]['momentum_buffer'], m)
     accepted, _ = opt.maybe_reject(float("-inf"))           # ... and never for -inf
     assert not accepted
+
+
+@pytest.mark.parametrize("model_name,shape", [("googleresnet", (3, 32, 32)), ("classificationconvnet", (784,))])
+def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape, monkeypatch):
+    """graphed.ConcurrentAccumulate (minibatches of the exact full-data gradient on two streams, BatchNorm statistics
+    logged and replayed in order) against the one-stream pass AT THE SAME PARAMETERS and on the same batches, incl. a
+    ragged last one: loss and gradient to rounding (another summation order over the minibatches), running statistics
+    and batch counters EXACTLY (the replay is the sequential update's arithmetic).  (Same runner for both: at a random
+    initialisation this net's gradient moves by 0.6 % under a one-ulp change of the parameters, so two runner
+    instances whose initial gradients differ in the last bit cannot be compared.)"""
+    from bnn_priors_amd import graphed
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(21)
+    n, bs = 7 * 128 + 40, 128
+    x = torch.randn((n,) + shape, generator=g).to(dev)
+    y = torch.randint(0, 10, (n,), generator=g).to(dev)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=bs, shuffle=False)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:128], y[:128]), batch_size=bs)
+    model = RC.make_net(models, x[:2].cpu(), torch.tensor([0, 9]), device=dev, cfg=dict(model=model_name))
+    torch.manual_seed(RC.SEED)
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, learning_rate=0.002, temperature=1.0, momentum=0.98,
+        reject_samples=True, metrics_saver=MemoryMetrics(), model_saver=None, seed=RC.SEED, chain_id=0,
+        cycle_seed=RC.CYCLE_SEED, use_graph=True, **RC.RUN_KW)
+    runner.begin()
+    pot = runner._potential()
+    batches = list(train)
+    buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
+    results = []
+    for lanes in (1, 2):
+        monkeypatch.setattr(graphed, "EXACT_LANES", lanes)
+        pot._exact_acc = None
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                if k in buffers:
+                    v.copy_(buffers[k])
+        outs = []
+        for _ in range(2):                                  # second pass: the captured lanes are reused
+            loss, log_prior, potential = pot.exact(batches)
+            torch.cuda.synchronize()
+            outs.append((loss.item(), potential.item(), [p.grad.clone() for p in pot.opt.engine.params],
+                         {k: v.clone() for k, v in model.state_dict().items() if k in buffers}))
+        assert isinstance(pot._exact_acc, graphed.ConcurrentAccumulate if lanes == 2 else graphed.GraphedAccumulate)
+        results.append(outs)
+    for (l1, u1, g1, b1), (l2, u2, g2, b2) in zip(*results):
+        assert abs(l1 - l2) <= 1e-9 * abs(l1) and abs(u1 - u2) <= 1e-9 * abs(u1)
+        for a, b in zip(g1, g2):
+            torch.testing.assert_close(a, b, rtol=0, atol=2e-6 * max(1e-30, b.abs().max().item()))
+        assert sorted(b1) == sorted(b2)
+        for k in b1:
+            assert torch.equal(b1[k], b2[k]), k
+    if buffers:      # the statistics did advance (8 minibatches per pass)
+        assert any(not torch.equal(results[0][0][3][k], buffers[k]) for k in buffers)
