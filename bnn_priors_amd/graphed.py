@@ -361,6 +361,7 @@ class GraphedAccumulate:
 
 # ------------------------------------------------------------------ the exact pass on several streams
 EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "2"))
+LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
 
 class ConcurrentAccumulate:
@@ -377,7 +378,7 @@ class ConcurrentAccumulate:
     minibatches in another order, so the two agree to rounding, not bit for bit).  Off-shape minibatches (the ragged
     last one) are evaluated eagerly, in order, after the lanes have been joined."""
 
-    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=512):
+    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=None):
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.model = potential.model
         dev = self.dev = self.eng.device
@@ -398,7 +399,8 @@ class ConcurrentAccumulate:
                 self.lanes.append(GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots))
                 self.log_cur.append(cur)
             main.wait_stream(s)
-        self.log_all = torch.zeros((capacity,) + tuple(self.log_cur[0].shape), dtype=torch.float64, device=dev)
+        self.log_all = torch.zeros((capacity or LOG_CAPACITY,) + tuple(self.log_cur[0].shape), dtype=torch.float64,
+                                   device=dev)
         self.loss = self.lanes[0].loss
         self.count = self.logged_from = 0
 

@@ -86,8 +86,9 @@ def test_rejected_proposal_restores_the_saved_state_exactly_at_googleresnet_size
     assert not accepted
 
 
-@pytest.mark.parametrize("model_name,shape", [("googleresnet", (3, 32, 32)), ("classificationconvnet", (784,))])
-def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape, monkeypatch):
+@pytest.mark.parametrize("model_name,shape,log_capacity", [("googleresnet", (3, 32, 32), 512), ("googleresnet", (3, 32, 32), 3),
+                                                          ("classificationconvnet", (784,), 512)])
+def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape, log_capacity, monkeypatch):
     """graphed.ConcurrentAccumulate (minibatches of the exact full-data gradient on two streams, BatchNorm statistics
     logged and replayed in order) against the one-stream pass AT THE SAME PARAMETERS and on the same batches, incl. a
     ragged last one: loss and gradient to rounding (another summation order over the minibatches), running statistics
@@ -95,6 +96,7 @@ def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape
     initialisation this net's gradient moves by 0.6 % under a one-ulp change of the parameters, so two runner
     instances whose initial gradients differ in the last bit cannot be compared.)"""
     from bnn_priors_amd import graphed
+    monkeypatch.setattr(graphed, "LOG_CAPACITY", log_capacity)     # 3: the log fills up and is replayed mid-pass
     dev = "cuda:0"
     g = torch.Generator().manual_seed(21)
     n, bs = 7 * 128 + 40, 128
