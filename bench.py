@@ -89,9 +89,9 @@ def parse():
     ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
     ap.add_argument("--chain-sweep", default="1,2,4,8",
                     help="densenet only: aggregate steps/s of K chains sharing ONE GPU's launches (MultiChainDense); '' = skip")
-    ap.add_argument("--stream-chains", default="",
+    ap.add_argument("--stream-chains", default=None,
                     help="googleresnet / convnet: aggregate steps/s of K chains on K HIP streams of ONE GPU, e.g. '1,2,3' "
-                         "(after the timed region; off by default)")
+                         "(after the timed region; default: '1,2' for a one-GPU googleresnet run, '' = skip)")
     return ap.parse_args()
 
 
@@ -698,9 +698,16 @@ def main():
             out["roofline_flat_arena"] = flat_arena_point(args.sweep_log2, device)
         if args.workload == "densenet" and args.chain_sweep and args.inference == "VerletSGLDReject":
             out["chains_per_gpu"] = chains_per_gpu_sweep(args, device, rank, [int(k) for k in args.chain_sweep.split(",")])
-        if args.workload != "densenet" and args.stream_chains and args.inference == "VerletSGLDReject":
-            out["chains_per_gpu"] = dict(chains_per_gpu_streams(args, device, rank, [int(k) for k in args.stream_chains.split(",")]),
-                                         method="K runners, each with its own captured step on its own HIP stream")
+        stream_chains = args.stream_chains
+        if stream_chains is None:
+            stream_chains = "1,2" if (args.workload == "googleresnet" and world == 1 and not args.eager) else ""
+        if args.workload != "densenet" and stream_chains and args.inference == "VerletSGLDReject":
+            try:
+                out["chains_per_gpu"] = dict(
+                    chains_per_gpu_streams(args, device, rank, [int(k) for k in stream_chains.split(",")]),
+                    method="K runners, each with its own captured step on its own HIP stream (no augmentation gather)")
+            except Exception as exc:       # an extension after the timed region: never takes the bench line down
+                out["chains_per_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]
