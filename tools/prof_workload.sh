@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- \
   python $REPO/bench.py --workload $WL --steps $STEPS --warmup $WARM --min-seconds 0.01 --cpu-budget 0 --sweep-log2 0 \
-  --samples 0 --no-kernel-timing "$@" > $OUT/bench.json 2> $OUT/bench.err
+  --samples 0 --no-kernel-timing --stream-chains "" "$@" > $OUT/bench.json 2> $OUT/bench.err
 cd $REPO && python tools/step_summary.py $OUT/kt_kernel_trace.csv --steps 40 > $OUT/steady_state_summary.txt
 rm -f $OUT/kt_kernel_trace.csv
 cat $OUT/steady_state_summary.txt; cat $OUT/bench.json
