@@ -320,11 +320,13 @@ class MultiChainDense:
         self._host = (_hip.DenseChain * K)()
         self._dev = torch.zeros(ctypes.sizeof(self._host), dtype=torch.uint8, device=self.device)
         self._uploaded = None
+        self._sig = None
         self._idx16 = np.zeros((K, _hip.MLP_BATCH_MULTI), dtype=np.uint16)
 
     def _table(self, batch):
         "per-chain pointers, uploaded when any of them changed (first use, roll-back arrays allocated, ...)"
-        for c, s in enumerate(self.steppers):
+        sig = [batch]
+        for s in self.steppers:
             st = s._by_batch.get(batch)
             if st is None:
                 st = s._by_batch[batch] = s._setup(batch)
@@ -332,6 +334,13 @@ class MultiChainDense:
             s._bind_grads()
             if s.eng._seg_dirty or s.eng._precond_dirty:
                 s.eng.refresh(s.opt._preconditioners())
+            sig.append(id(st))
+            sig.append(bytes(s.eng.layout))        # (pointers of the arenas / roll-back arrays: 100-odd bytes)
+        if sig == self._sig:                       # nothing moved since the table was last built: the usual step
+            return
+        self._sig = sig
+        for c, s in enumerate(self.steppers):
+            st = s._by_batch[batch]
             row = self._host[c]
             ctypes.memmove(ctypes.addressof(row.mlp), ctypes.addressof(st["mlp"]), ctypes.sizeof(_hip.MlpArgs))
             ctypes.memmove(ctypes.addressof(row.layout), ctypes.addressof(s.eng.layout), ctypes.sizeof(_hip.Layout))
@@ -372,13 +381,13 @@ class MultiChainDense:
             s.eng.energy_ready = True
         if not metrics:
             return None
-        out = []
         for s in self.steppers:
-            eng = s.eng
-            eng.flush()                      # this chain's bookkeeping, now (the row reads its results)
-            eng.metrics_ready = True
-            v = eng.report.cpu().numpy()
+            s.eng.flush()                    # every chain's bookkeeping, now (the rows read its results) ...
+            s.eng.metrics_ready = True
+        rows = torch.stack([s.eng.report for s in self.steppers]).cpu().numpy()      # ... and ONE read-back for all
+        out = []
+        for s, v in zip(self.steppers, rows):
             out.append(dict(loss=float(v[4]), acc=float(v[5]), nonfinite=bool(v[1] != 0.0), log_prior=float(v[2]),
                             energy=float(v[3])))
-            eng._state_host = v[8:].reshape(eng.n_seg, -1).copy()
+            s.eng._state_host = v[8:].reshape(s.eng.n_seg, -1).copy()
         return out
