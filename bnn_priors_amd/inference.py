@@ -329,6 +329,13 @@ class SGLDRunner:
     # ------------------------------------------------------------------ the run
     def run(self, progressbar=False):
         "inference.py:110-187"
+        for _ in self.run_iter():
+            pass
+
+    def run_iter(self):
+        """``run()`` as a generator that yields after every minibatch step (and once per epoch end): what
+        ``multichain.run_on_streams`` interleaves to drive several chains on several HIP streams of one GPU from
+        one process.  Exhausting it IS ``run()``."""
         self.optimizer = self._make_optimizer(self._params)
         self.optimizer.sample_momentum()
         self.scheduler = self._make_scheduler(self.optimizer)
@@ -345,6 +352,7 @@ class SGLDRunner:
                     store_metrics = (i == 0 or step % self.metrics_skip == 0)
                     initial_step = (step == 0 or (i == 0 and self._is_sampling_epoch(epoch - 1)))
                     self.step(step, x, y, store_metrics=store_metrics, initial_step=initial_step)
+                    yield step
                 # rows still in flight were produced with the CURRENT preconditioners: log them first
                 self._drain_rows()
                 if self.precond_update is not None and epoch % self.precond_update == 0:
@@ -355,6 +363,7 @@ class SGLDRunner:
                     self._save_sample(state_dict, cycle, epoch, step)
                 self._evaluate_model(state_dict, step)
                 self.metrics_saver.flush(every_s=10)
+                yield step
         self._drain_rows()
         # metrics for the last sample (inference.py:182-187)
         x, y = next(iter(self._batches()))

@@ -134,8 +134,8 @@ class VerletSGLDRunnerReject(SGLDRunner):
         self._total_energy = 0.
         return 0
 
-    def run(self, progressbar=False):
-        "inference_reject.py:35-179"
+    def run_iter(self):
+        "inference_reject.py:35-179 as a generator (see SGLDRunner.run_iter): yields after every leapfrog step / epoch end"
         step = self.begin()
         opt, batches = self.optimizer, self._batches()
 
@@ -165,6 +165,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                         step += 1
                         acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
                         step = self._after_leapfrog(step, acc, batches, last_of_epoch=(i == n_batches - 1))
+                        yield step
 
                     self._drain_rows()
                     if self._is_sampling_epoch(epoch):
@@ -177,6 +178,7 @@ class VerletSGLDRunnerReject(SGLDRunner):
                         opt.update_preconditioner()
                     self._check_finite()
                     self.metrics_saver.flush(every_s=30)
+                    yield step
         finally:
             self.dataloader.sampler.generator = None
 

@@ -282,3 +282,48 @@ def test_hmc_trajectories_and_temperature_on_gpu(T):
         r2, _ = _trajectory_runner(inference_reject.HMCRunnerReject, 0.5, 3, device="cuda:0")
         r2.tempered = False
         r2.run()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["VerletSGLDReject_googleresnet", "VerletSGLDReject_convnet_laplace", "HMCReject"])
+def test_chains_interleaved_on_streams_equal_chains_run_alone(name):
+    """multichain.run_on_streams: two chains (chain_id 0, 1), each on its own HIP stream of the one GPU, advanced step by
+    step from one process -- every chain's metric streams and samples are bit-identical to the same chain's ``run()``.
+    (As in the reference, the INITIAL full-data pass iterates the shuffling loader before the per-cycle seed exists, i.e.
+    it draws its order from torch's global generator -- and BatchNorm makes the potential depend on the batches'
+    composition -- so each chain re-seeds the global generator where it begins, in both modes.)"""
+    from bnn_priors_amd import multichain
+    cfg = RC.CASES[name]
+    dev = "cuda:0"
+
+    def make(chain):
+        train, test, (x, y) = RC.make_data(dev, cfg=cfg)
+        model = RC.make_net(models, x, y, device=dev, cfg=cfg)
+        metrics = MemoryMetrics()
+        runner = _runner_class(name)(
+            model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+            temperature=cfg["temperature"], momentum=cfg["momentum"], reject_samples=cfg["reject_samples"],
+            metrics_saver=metrics, model_saver=None, seed=RC.SEED, chain_id=chain, cycle_seed=RC.CYCLE_SEED,
+            **RC.RUN_KW)
+        begin = runner.begin
+        runner.begin = lambda: (torch.manual_seed(RC.SEED + chain), begin())[1]
+        return runner, metrics
+
+    alone = []
+    for chain in (0, 1):
+        runner, metrics = make(chain)
+        runner.run()
+        alone.append((RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}))
+    pairs = [make(chain) for chain in (0, 1)]
+    multichain.run_on_streams([r for r, _ in pairs])
+    for chain, (runner, metrics) in enumerate(pairs):
+        s1, p1 = RC.streams_of(metrics), runner.get_samples()
+        s0, p0 = alone[chain]
+        assert sorted(s0) == sorted(s1)
+        for k in s0:
+            if k == "timestamps":
+                continue
+            assert np.array_equal(s0[k][0], s1[k][0]) and np.array_equal(s0[k][1], s1[k][1]), (chain, k)
+        for k in p0:
+            assert torch.equal(p0[k], p1[k]), (chain, k)
+    assert not np.array_equal(alone[0][0]["potential"][1], alone[1][0]["potential"][1])     # the chains do differ
