@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")]
 SOURCE = SOURCES[0]
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CHUNK = 4096
 CHUNK_SMALL = 1024
 NSUMS = 6
@@ -56,7 +56,7 @@ class Layout(ctypes.Structure):
                 ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("prev_theta", ctypes.c_void_p),
                 ("prev_g", ctypes.c_void_p), ("prev_m", ctypes.c_void_p),
                 ("partials", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("scalars", ctypes.c_void_p)]
+                ("scalars", ctypes.c_void_p), ("prior_flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class StepArgs(ctypes.Structure):

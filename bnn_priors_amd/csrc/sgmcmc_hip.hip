@@ -1101,6 +1101,8 @@ int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_
   if (L->chunk_elems != SGMCMC_CHUNK && L->chunk_elems != SGMCMC_CHUNK_SMALL) return (int)hipErrorInvalidValue;
   // the in-flight prior exists for the graph-replay kernel on float32 arenas only
   if ((A->flags & SGMCMC_INLINE_PRIOR) && (!Ad || G || L->dtype != SGMCMC_F32)) return (int)hipErrorInvalidValue;
+  // ... and, like the gradient-assembling kernels, carries the lean prior code only
+  if (((A->flags & SGMCMC_INLINE_PRIOR) || G) && L->prior_flags != 0) return (int)hipErrorInvalidValue;
   const bool vec = !(A->flags & SGMCMC_UNALIGNED);
   const bool small = L->chunk_elems == SGMCMC_CHUNK_SMALL;
   if (L->dtype == SGMCMC_F32) {
@@ -1315,6 +1317,7 @@ int sgmcmc_prior_grad(const sgmcmc_layout* L, double num_data, int calc_log_prob
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
+  flags |= L->prior_flags;
   const bool full = (flags & (SGMCMC_PRIOR_HAS_LINKS | SGMCMC_PRIOR_FULL)) != 0;
   if (L->dtype == SGMCMC_F32) {
     if (full) SGMCMC_LAUNCH((prior_kernel<float, true>), grid, block, 0, s, *L, num_data, calc_log_prob, none);
@@ -1342,6 +1345,7 @@ int sgmcmc_grad_reduce_prior(const sgmcmc_layout* L, const float* gpart, int n_s
   if (!L || L->n_chunks <= 0 || !(num_data > 0) || !gpart || n_slices <= 0 || batch <= 0 ||
       L->dtype != SGMCMC_F32)
     return (int)hipErrorInvalidValue;
+  if (L->prior_flags != 0) return (int)hipErrorInvalidValue;  // lean prior code only (prior_body<T, false>)
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)L->n_chunks), block(kThreads);
   const GradParts G = {gpart, n_slices, stride, loss_part, correct_part, batch, num_data};

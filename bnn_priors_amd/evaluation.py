@@ -15,8 +15,8 @@ instead of gathering [E, N, C] from every GPU.
 """
 import contextlib
 import math
-
 import os
+import warnings
 
 import torch
 
@@ -37,6 +37,10 @@ def _n_samples(samples):
     return min(len(v) for v in samples.values())
 
 
+class _NotBatchable(Exception):
+    "the grouped (vmap) evaluation cannot run this model / these samples: evaluate sample by sample instead"
+
+
 BATCHED = os.environ.get("SGMCMC_EVAL_BATCHED", "1") != "0"   # stack the samples: ONE grouped forward per test batch
 SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation memory at E_group * batch images
 
@@ -45,7 +49,10 @@ SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation mem
 def _plain_torch_layers():
     """torch.func.vmap batches ATen operators, not this package's custom-kernel autograd functions: inside the
     grouped forward the layers take their ATen route (the grouped evaluation is a throughput problem -- E samples x
-    a test batch per launch -- that the library's batched convolutions / GEMMs handle well)."""
+    a test batch per launch -- that the library's batched convolutions / GEMMs handle well).
+    The switch is process-wide but never observable by another chain: the block runs to completion inside ONE
+    ``next()`` of a runner's generator (multichain.run_on_streams interleaves chains only at ``yield`` points, and
+    nothing in here yields), on one Python thread."""
     from . import bn, conv, pool, resblock
     mods = (bn, conv, pool, resblock)
     old = [m.ENABLED for m in mods]
@@ -72,10 +79,10 @@ def _predictive_tables_batched(model, dataloader_test, samples, labels, E, C):
     names = set(dict(model.named_parameters())) | set(dict(model.named_buffers()))
     state = {k: v[:E].to(device) for k, v in samples.items() if k in names}
     if set(state) != names:
-        raise KeyError("samples do not cover the model's state")
+        raise _NotBatchable("the samples do not cover the model's state")
     temp = model.softmax_temp
     if callable(temp) or isinstance(temp, torch.Tensor):
-        raise TypeError("batched evaluation needs a plain-number softmax temperature")
+        raise _NotBatchable("the softmax temperature is not a plain number")
 
     def logits_of(st, x):
         return functional_call(model.net, {k[len("net."):]: v for k, v in st.items()}, (x,))
@@ -87,7 +94,15 @@ def _predictive_tables_batched(model, dataloader_test, samples, labels, E, C):
             j = i + len(bx)
             for e0 in range(0, E, SAMPLE_GROUP):
                 e1 = min(E, e0 + SAMPLE_GROUP)
-                f = grouped({k: v[e0:e1] for k, v in state.items()}, bx)               # [e, B, C]
+                try:
+                    f = grouped({k: v[e0:e1] for k, v in state.items()}, bx)           # [e, B, C]
+                except RuntimeError as exc:
+                    # only vmap's own refusals fall back (an operator without a batching rule, in-place writes to
+                    # an unbatched tensor, data-dependent control flow); out-of-memory and real bugs propagate
+                    msg = str(exc)
+                    if any(t in msg for t in ("vmap", "batching rule", "Batching rule", "functorch")):
+                        raise _NotBatchable(msg.splitlines()[0]) from exc
+                    raise
                 logp = torch.log_softmax(f / temp, dim=-1)        # Categorical(logits=...).logits, in the net's dtype
                 acc[e0:e1, i:j] = logp
                 lps[e0:e1, i:j] = logp.gather(-1, by.view(1, -1, 1).expand(e1 - e0, -1, 1)).squeeze(-1)
@@ -108,9 +123,12 @@ def predictive_tables(model, dataloader_test, samples):
             and not model.training and device.type == "cuda"):
         try:
             lps, acc = _predictive_tables_batched(model, dataloader_test, samples, labels, E, C)
+        except _NotBatchable as exc:
+            warnings.warn(f"grouped posterior-predictive evaluation unavailable ({exc}); evaluating sample by sample")
+        else:
+            # the reference leaves the model holding the LAST sample (exp_utils.py:262-264 loads each in turn)
+            model.load_state_dict({k: v[E - 1] for k, v in samples.items()})
             return lps, acc, labels, "cat"
-        except (RuntimeError, NotImplementedError, KeyError, TypeError):
-            pass            # an operator without a batching rule, odd state: sample by sample below
     lps = torch.zeros((E, N), dtype=torch.float64, device=device)
     acc = torch.zeros((E, N, C), dtype=torch.float64, device=device)
     kind = None

@@ -316,6 +316,8 @@ class MultiChainDense:
                 raise ValueError("chains must share one architecture")
             if s.X.shape[0] > 65536:
                 raise ValueError("16-bit row indices: data sets of up to 65,536 rows")
+            if s.eng.prior_flags() != 0:
+                raise ValueError("the multi-chain kernels carry the lean prior code only (kinds <= CAUCHY, no links)")
         self.lib, self.device = s0.lib, s0.eng.device
         self._host = (_hip.DenseChain * K)()
         self._dev = torch.zeros(ctypes.sizeof(self._host), dtype=torch.uint8, device=self.device)
@@ -369,6 +371,15 @@ class MultiChainDense:
                 raise RuntimeError("chains stepped together must share the schedule and the draw counter")
         for c, idx in enumerate(idx_list):
             self._idx16[c, :batch] = idx
+        # the launch finalizes ONE deferred transition for all chains: they must agree on what is pending.  A chain
+        # flushed on its own (a state read, a preconditioner refresh) while another was not would otherwise have its
+        # bookkeeping run twice -- or the others' dropped: settle every chain first.
+        pend = [s.eng.pending for s in self.steppers]
+        p0 = pend[0]
+        if any((p is None) != (p0 is None) or (p is not None and (p.draw != p0.draw or p.flags != p0.flags))
+               for p in pend[1:]):
+            for s in self.steppers:
+                s.eng.flush()
         pending = s0.eng.pending
         idx16 = np.ascontiguousarray(self._idx16[:, :batch])
         err = self.lib.sgmcmc_dense_step_multi(self._dev.data_ptr(), ctypes.byref(self._host[0]), K, A,

@@ -81,9 +81,10 @@ class VerletSGLDRunnerReject(SGLDRunner):
         fn = getattr(self.optimizer, "delta_energy_of_last_transition", self.optimizer.delta_energy)
         return fn(self._initial_potential, potential)
 
-    def _after_leapfrog(self, step, acc, batches, last_of_epoch):
-        "hook for runners that end trajectories inside an epoch (HMCRunnerReject(trajectory_length=L))"
-        return step
+    def _trajectory_ends(self, last_of_epoch, epoch):
+        """hook for runners that end trajectories inside an epoch (HMCRunnerReject(trajectory_length=L)): called once
+        per leapfrog step BEFORE it runs; True = this step is followed by an M-H point of its own"""
+        return False
 
     def _mh_point(self, step, acc, batches, save=None):
         """End of a trajectory: exact full-data gradient, ``final_step``, energy difference, Metropolis-Hastings
@@ -161,10 +162,18 @@ class VerletSGLDRunnerReject(SGLDRunner):
                     # same minibatch order in every epoch of the cycle (:84)
                     generator.set_state(cycle_random_state)
                     n_batches = len(batches)
+                    lr_stepped = False
                     for i, (x, y) in enumerate(self._hot_batches()):
                         step += 1
-                        acc = self.leapfrog(step, x, y, last_of_epoch=(i == n_batches - 1))
-                        step = self._after_leapfrog(step, acc, batches, last_of_epoch=(i == n_batches - 1))
+                        last = i == n_batches - 1
+                        # a step that ends a trajectory is treated like the last one of an epoch: the learning
+                        # rate advances AFTER the final_step that closes it (:146), exactly once per minibatch
+                        ends = self._trajectory_ends(last, epoch)
+                        acc = self.leapfrog(step, x, y, last_of_epoch=last or ends)
+                        if ends:
+                            self._drain_rows()
+                            step = self._mh_point(step, acc, batches)
+                            lr_stepped = last
                         yield step
 
                     self._drain_rows()
@@ -172,7 +181,8 @@ class VerletSGLDRunnerReject(SGLDRunner):
                         step = self._mh_point(step, acc, batches, save=(cycle, epoch))
                     else:
                         self._evaluate_model(self.model.state_dict(), step)
-                        self.scheduler.step()
+                        if not lr_stepped:      # (an M-H point on the epoch's last step already advanced it)
+                            self.scheduler.step()
 
                     if self.precond_update is not None and (epoch + 1) % self.precond_update == 0:
                         opt.update_preconditioner()
@@ -190,6 +200,8 @@ class HMCRunnerReject(VerletSGLDRunnerReject):
     ``trajectory_length=L``: a trajectory ends -- exact gradient, ``final_step``, M-H test, momentum refresh,
     ``initial_step`` -- after every L leapfrog steps as well as at the end of every sampling epoch (where the sample
     is stored, as in the reference).  Intra-epoch M-H points log a metrics row with ``acceptance/is_sample = 0``.
+    The learning-rate schedule advances once per minibatch whatever L is (the step that ends a trajectory hands its
+    scheduler step to the M-H point, as an epoch's last step does in the reference, :113,146).
     ``tempered=True``: allows ``temperature != 1`` (samples exp(-U/T); see mcmc/hmc.py here)."""
 
     def __init__(self, *a, trajectory_length=None, tempered=False, **kw):
@@ -211,18 +223,15 @@ class HMCRunnerReject(VerletSGLDRunnerReject):
         opt.defer_nan_check = True
         return opt
 
-    def _after_leapfrog(self, step, acc, batches, last_of_epoch):
+    def _trajectory_ends(self, last_of_epoch, epoch):
         if self.trajectory_length is None:
-            return step
+            return False
         self._since_mh += 1
-        if last_of_epoch:
-            # a sampling epoch's end is an M-H point of its own (run()): the count restarts there
-            return step
-        if self._since_mh >= self.trajectory_length:
-            self._since_mh = 0
-            self._drain_rows()
-            step = self._mh_point(step, acc if acc is not None else getattr(self, "_last_acc", 0.), batches)
-        return step
+        if last_of_epoch and self._is_sampling_epoch(epoch):
+            # a SAMPLING epoch's end is an M-H point of its own (run_iter): the count restarts there.  Any other
+            # epoch's end is an ordinary step boundary: the count runs on across it and may end exactly on it.
+            return False
+        return self._since_mh >= self.trajectory_length
 
     def _mh_point(self, step, acc, batches, save=None):
         self._since_mh = 0

@@ -251,7 +251,14 @@ class Engine:
                     row["scale_link"] = links[i] + 1
                     self.prior_links = True
         self.prior_max_kind = max([0] + [int(sp[0]) for sp in specs if sp is not None])
+        # the layout says which prior code its table needs: lean-only entry points refuse the rest (no silent
+        # Student-t evaluation of a generalised normal, no NaN placeholder scale of a linked segment)
+        self.layout.prior_flags = self.prior_flags()
         self._seg_dirty = True
+
+    def prior_flags(self):
+        return ((_hip.PRIOR_HAS_LINKS if self.prior_links else 0)
+                | (_hip.PRIOR_FULL if self.prior_max_kind > _hip.PRIOR_CAUCHY else 0))
 
     prior_links = False      # some segment takes its scale from a hyper segment
     prior_max_kind = 0
@@ -380,8 +387,7 @@ class Engine:
         self.flush()
         _hip.check(self.lib.sgmcmc_prior_grad(ctypes.byref(self.layout), float(num_data),
                                               int(bool(calc_log_prob)),
-                                              (_hip.PRIOR_HAS_LINKS if self.prior_links else 0)
-                                              | (_hip.PRIOR_FULL if self.prior_max_kind > _hip.PRIOR_CAUCHY else 0),
+                                              self.prior_flags(),
                                               self.stream()),
                    "sgmcmc_prior_grad")
         if calc_log_prob:

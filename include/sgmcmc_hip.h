@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 4
+#define SGMCMC_ABI_VERSION 5
 #define SGMCMC_CHUNK 4096 /* default elements per arena chunk = 256 threads x 4 items x 4 elements */
 #define SGMCMC_CHUNK_SMALL 1024 /* small models: one item per thread, 4x more workgroups */
 #define SGMCMC_NSUMS 6
@@ -132,6 +132,11 @@ typedef struct {
                               [2] fused log-prior total, [3] energy total of the last transition
                               (SGMCMC_SMALL_FINALIZE only), [4] minibatch loss, [5] minibatch
                               accuracy (sgmcmc_grad_reduce_prior) */
+  uint32_t prior_flags;    /* SGMCMC_PRIOR_HAS_LINKS | SGMCMC_PRIOR_FULL as they hold for THIS segment table: the
+                              entry points that only carry the lean prior code (sgmcmc_grad_reduce_prior, the
+                              gradient-assembling step kernels, SGMCMC_INLINE_PRIOR) return hipErrorInvalidValue
+                              when either bit is set instead of evaluating a family they do not implement */
+  uint32_t reserved;
 } sgmcmc_layout;
 
 /* Scalars of one transition of one parameter group, computed by the host in

@@ -269,6 +269,33 @@ def test_hmc_trajectory_length_host_logic():
     _check_trajectory_streams(metrics, runner, 3)
 
 
+def test_hmc_trajectory_ending_on_a_warmup_epochs_last_step_and_the_lr_schedule():
+    """L = 4 divides the 8 minibatches of an epoch: a trajectory ends exactly on the last step of the warm-up epoch
+    (no sample is stored there, so the M-H point is the trajectory's own) -- every trajectory has exactly L steps --
+    and the learning rate advances once per minibatch whatever L is: the lr logged at a stored sample equals the lr
+    of a run without intra-epoch trajectories."""
+    cls = _with_oracle_sampler(inference_reject.HMCRunnerReject)
+    runner, metrics = _trajectory_runner(cls, 1.0, 4)
+    runner.run()
+    got = RC.streams_of(metrics)
+    steps, _ = got["acceptance/rejected"]
+    # leapfrog 1-4 | M-H 5 | 6-9 (9 = last of the warm-up epoch) | M-H 10 | 11-14 | M-H 15 | 16-19 | sample 20 | ...
+    assert steps.tolist() == [0, 5, 10, 15, 20, 25, 30, 35, 40]
+    s_all, is_sample = got["acceptance/is_sample"]
+    assert s_all[is_sample == 1].tolist() == [0, 20, 40]
+    plain, plain_metrics = _trajectory_runner(cls, 1.0, None)
+    plain.run()
+    ref = RC.streams_of(plain_metrics)
+    lr = dict(zip(*got["lr"]))
+    lr_ref = dict(zip(*ref["lr"]))
+    ref_samples = ref["acceptance/is_sample"][0][ref["acceptance/is_sample"][1] == 1]
+    assert ref_samples.tolist() == [0, 17, 34]
+    for a, b in zip([0, 20, 40], ref_samples.tolist()):
+        assert lr[a] == lr_ref[b], (a, b, lr[a], lr_ref[b])      # bit-exact host doubles
+    # and the scheduler has advanced exactly once per minibatch + once at construction
+    assert runner.scheduler.last_epoch == plain.scheduler.last_epoch == 2 * 2 * 8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("T", [1.0, 0.1])
 def test_hmc_trajectories_and_temperature_on_gpu(T):
