@@ -29,14 +29,15 @@ def _runner_class(name):
     return inference_reject.runner_class(RC.CASES[name].get("runner", name))
 
 
-def _check(name, metrics, runner, rtol, atol, de_atol, acc_atol=0.0):
+def _check(name, metrics, runner, rtol, atol, de_atol, acc_atol=0.0, cfg_rtol=None, cfg_atol=0.0):
+    cfg_rtol = rtol if cfg_rtol is None else cfg_rtol
     g = gold()
     got = RC.streams_of(metrics)
     want_keys = sorted({k.split("/", 1)[1].rsplit("/", 1)[0] for k in g
                         if k.startswith(name + "/") and k.endswith("/steps")})
-    got_keys = sorted(k for k in got if not k.startswith(("preconditioner/", "est_temperature/net",
-                                                           "est_config_temp/net")))
-    assert got_keys == want_keys
+    # all 3 * n_tensors + 12 keys of store_metrics (inference.py:262-294), the per-parameter ones included
+    assert sorted(got) == want_keys
+    assert sum(k.startswith("preconditioner/") for k in want_keys) == len(runner.param_names)
     for k in want_keys:
         s, v = got[k]
         gs, gv = g[f"{name}/{k}/steps"], g[f"{name}/{k}/values"]
@@ -47,9 +48,15 @@ def _check(name, metrics, runner, rtol, atol, de_atol, acc_atol=0.0):
             fin = np.isfinite(gv)
             assert np.array_equal(np.isfinite(v), fin), (name, k)
             at = de_atol if k in ("delta_energy", "total_energy") else atol
+            rt = rtol
             if k in ("acc", "test/acc"):
                 at = max(at, acc_atol)    # discrete: one near-tie argmax flips 1/128 (1/256)
-            np.testing.assert_allclose(v[fin], gv[fin], rtol=rtol, atol=at, err_msg=f"{name}:{k}")
+            if k.startswith("est_config_temp/") and k != "est_config_temp/all":
+                # (theta . g) N / d of ONE tensor: a sum of d signed terms that cancels to a small multiple of
+                # sqrt(d) of them (biases: d = 10..64), scaled by N -- gradient rounding of the other device's
+                # reduction order shows up relative to the terms' magnitude, not to the cancelled result
+                rt, at = cfg_rtol, max(at, cfg_atol * max(1.0, float(np.abs(gv[fin]).max())))
+            np.testing.assert_allclose(v[fin], gv[fin], rtol=rt, atol=at, err_msg=f"{name}:{k}")
     samples = runner.get_samples()
     first = next(iter(k for k in samples if k.endswith("weight_prior.p")))
     np.testing.assert_allclose(samples[first].reshape(samples[first].shape[0], -1)[:, :16].cpu().numpy(),
@@ -106,7 +113,7 @@ def test_runner_host_logic_matches_reference_goldens(name):
         **RC.RUN_KW, **({"cycle_seed": RC.CYCLE_SEED} if "Reject" in name else {}))
     runner.run()
     # same torch-CPU ops, same noise: near bit equality
-    _check(name, metrics, runner, rtol=1e-5, atol=1e-6, de_atol=2e-2)
+    _check(name, metrics, runner, rtol=1e-5, atol=1e-6, de_atol=2e-2, cfg_rtol=1e-3, cfg_atol=1e-4)
 
 
 # ------------------------------------------------------------------ GPU: end to end
@@ -130,7 +137,7 @@ def test_runner_on_gpu_matches_reference_goldens(name):
     # inside _check.  Floats: N = 1024 multiplies one fp32 ulp of the potential (U ~ 60) into
     # ~8e-3 of delta_energy (inherent to the reference's formula); the
     # GPU's GEMM / reduction order differs from the CPU's, so allow a few of those.
-    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128)
+    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128, cfg_rtol=1e-2, cfg_atol=2e-3)
 
 
 @pytest.mark.gpu

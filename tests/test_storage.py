@@ -14,45 +14,57 @@ pytestmark = pytest.mark.skipif(not _h5.available(), reason="libhdf5 (>= 1.10) n
 H5DUMP = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
 
 
-def test_recorded_metrics_like_the_reference_test(tmp_path):
-    "test_exp_utils.py:27-80, with a SWMR reader opened while the writer still holds the file"
+INT_FILL = -2 ** 63          # what the store writes where an int64 column has no value (exp_utils.py:505-513)
+# the scenario of the reference's store test (testing/test_exp_utils.py:27-80) as a TABLE: column -> (stride, dtype).
+# A column receives a value at step -1 and at every multiple of its stride; 101 rows (steps -1 .. 99); chunk 13;
+# the writer flushes at multiples of 31 while a SWMR reader looks at the file.
+COLUMNS = {"re_step": (1, np.int64), "step5": (5, np.int64), "step11": (11, np.float64), "step23": (23, np.int64)}
+STEPS = np.arange(-1, 100)
+
+
+def _expected_column(stride, dtype):
+    "the dense column the file must hold: value step // stride where written, the dtype's fill everywhere else"
+    written = (STEPS == -1) | (STEPS % stride == 0)
+    fill = np.nan if dtype is np.float64 else INT_FILL
+    return np.where(written, STEPS // stride, fill).astype(dtype), written
+
+
+def test_metric_columns_equal_a_dense_model_of_the_reference_scenario(tmp_path):
+    """HDF5Metrics against a numpy model of what the reference's store must contain for its own test scenario:
+    every column compared WHOLE (values, fills, dtype), the row count a concurrent SWMR reader sees after each
+    flush, the chunking / checksum filter of the datasets."""
     fname = tmp_path / "metrics_test.h5"
+    seen_by_reader = {}
     with storage.HDF5Metrics(fname, "w", chunk_size=13) as metrics:
-        for step in range(-1, 100):
-            metrics.add_scalar("re_step", step, step)
-            if step == -1 or step % 5 == 0:
-                metrics.add_scalar("step5", step // 5, step)
-            if step == -1 or step % 11 == 0:
-                metrics.add_scalar("step11", float(step // 11), step)
-            if step == -1 or step % 23 == 0:
-                metrics.add_scalar("step23", step // 23, step)
+        for step in STEPS.tolist():
+            for key, (stride, dtype) in COLUMNS.items():
+                if step == -1 or step % stride == 0:
+                    metrics.add_scalar(key, dtype(step // stride).item(), step)
             if step % 31 == 0:
                 metrics.flush()
-                with _h5.File(fname, "r", swmr=True) as reader:
-                    for k in reader.keys():
-                        assert len(reader[k]) == step + 2
+                with _h5.File(fname, "r", swmr=True) as reader:        # the writer still holds the file
+                    seen_by_reader[step] = {k: len(reader[k]) for k in reader.keys()}
+    # a reader that opens mid-run sees every row flushed so far, in every column
+    assert sorted(seen_by_reader) == [0, 31, 62, 93]
+    for step, lengths in seen_by_reader.items():
+        assert set(lengths) == set(COLUMNS) | {"steps", "timestamps"}
+        assert set(lengths.values()) == {step + 2}, (step, lengths)
 
     with _h5.File(fname, "r") as f:
-        assert sorted(f.keys()) == ["re_step", "step11", "step23", "step5", "steps", "timestamps"]
-        for k in f.keys():
-            assert len(f[k]) == 101
-            if k != "timestamps":
-                assert f[k][0] == -1
-        assert np.all(~np.isnan(f["timestamps"][:]))
-        assert np.array_equal(f["steps"][:], np.arange(-1, 100))
-        assert np.array_equal(f["steps"][:], f["re_step"][:])
-        assert f["steps"].dtype == np.int64 and f["step11"].dtype == np.float64
-
-        assert np.array_equal(f["step5"][1::5], np.arange(100 // 5))
-        for i in range(1, 5):
-            assert np.all(f["step5"][1 + i::5] == -2 ** 63)
-        assert np.array_equal(f["step11"][1::11], np.arange(100 // 11 + 1).astype(np.float64))
-        for i in range(1, 11):
-            assert np.all(np.isnan(f["step11"][1 + i::11]))
-        assert np.array_equal(f["step23"][1::23], np.arange(100 // 23 + 1))
-        for i in range(1, 23):
-            assert np.all(f["step23"][1 + i::23] == -2 ** 63)
-        assert f["step5"].creation_properties() == ((13,), [3])        # filter 3 = Fletcher-32
+        assert sorted(f.keys()) == sorted(set(COLUMNS) | {"steps", "timestamps"})
+        assert np.array_equal(f["steps"][:], STEPS) and f["steps"].dtype == np.int64
+        ts = f["timestamps"][:]
+        assert ts.shape == (101,) and ts.dtype == np.float64 and not np.isnan(ts).any()
+        for key, (stride, dtype) in COLUMNS.items():
+            want, written = _expected_column(stride, dtype)
+            got = f[key][:]
+            assert got.dtype == dtype and got.shape == want.shape, key
+            assert np.array_equal(got[written], want[written]), key
+            if dtype is np.float64:
+                assert np.isnan(got[~written]).all(), key
+            else:
+                assert (got[~written] == INT_FILL).all(), key
+            assert f[key].creation_properties() == ((13,), [3]), key       # chunk 13; filter 3 = Fletcher-32
 
 
 def test_metrics_errors_and_nested_names(tmp_path):
