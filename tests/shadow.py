@@ -33,6 +33,17 @@ def _cpu(t):
     return t.detach().to("cpu", copy=True)
 
 
+def _cpu_all(tensors):
+    "host copies of a list of device tensors through ONE transfer (65 tensors x 7 arrays per step otherwise)"
+    tensors = [t.detach() for t in tensors]
+    flat = torch.cat([t.reshape(-1) for t in tensors]).cpu()
+    out, i = [], 0
+    for t in tensors:
+        out.append(flat[i:i + t.numel()].clone().reshape(t.shape))
+        i += t.numel()
+    return out
+
+
 class Shadow:
     def __init__(self, opt, params, names, seed, chain_id, kind, temperature, momentum, lr, num_data):
         self.opt, self.dev_params, self.names = opt, list(params), list(names)
@@ -53,15 +64,21 @@ class Shadow:
 
     def pull(self, grads=False):
         "shadow <- device: parameters, momentum, square_avg (and the gradient)"
-        for p, q in zip(self.dev_params, self.params):
-            st, sq = self._dev_state(p), self.ref.state[q]
-            q.data.copy_(_cpu(p))
-            if "momentum_buffer" in st:
-                sq["momentum_buffer"] = _cpu(st["momentum_buffer"])
-            sq["square_avg"] = _cpu(st["square_avg"])
+        states = [self._dev_state(p) for p in self.dev_params]
+        has_m = "momentum_buffer" in states[0]
+        theta = _cpu_all(self.dev_params)
+        mom = _cpu_all([st["momentum_buffer"] for st in states]) if has_m else None
+        v = _cpu_all([st["square_avg"] for st in states])
+        g = _cpu_all([p.grad for p in self.dev_params]) if grads else None
+        for i, (st, q) in enumerate(zip(states, self.params)):
+            sq = self.ref.state[q]
+            q.data.copy_(theta[i])
+            if has_m:
+                sq["momentum_buffer"] = mom[i].reshape(q.shape)
+            sq["square_avg"] = v[i].reshape(q.shape)
             sq["preconditioner"] = float(st["preconditioner"])
             if grads:
-                q.grad = _cpu(p.grad)
+                q.grad = g[i]
 
     def _sync_scalars(self, lr=None):
         g, gd = self.ref.param_groups[0], self.opt.param_groups[0]
@@ -71,15 +88,18 @@ class Shadow:
     def _check(self, what=("theta", "mom", "v")):
         "device results of the transition just made vs the shadow's"
         worst = self.log["max_err"]
-        for name, p, q in zip(self.names, self.dev_params, self.params):
-            st, sq = self._dev_state(p), self.ref.state[q]
-            pairs = dict(theta=(p, q), mom=(st.get("momentum_buffer"), sq.get("momentum_buffer")),
-                         v=(st["square_avg"], sq["square_avg"]))
+        states = [self._dev_state(p) for p in self.dev_params]
+        dev = dict(theta=_cpu_all(self.dev_params) if "theta" in what else None,
+                   mom=_cpu_all([st["momentum_buffer"] for st in states])
+                   if "mom" in what and "momentum_buffer" in states[0] else None,
+                   v=_cpu_all([st["square_avg"] for st in states]) if "v" in what else None)
+        for i, (name, q) in enumerate(zip(self.names, self.params)):
+            sq = self.ref.state[q]
+            refs = dict(theta=q, mom=sq.get("momentum_buffer"), v=sq["square_avg"])
             for k in what:
-                a, b = pairs[k]
-                if a is None:
+                if dev[k] is None:
                     continue
-                a, b = _cpu(a).double().numpy().ravel(), b.detach().double().numpy().ravel()
+                a, b = dev[k][i].double().numpy().ravel(), refs[k].detach().double().numpy().ravel()
                 scale = max(float(np.abs(b).max()), 1e-30)
                 err = float(np.abs(a - b).max()) / scale
                 worst[k] = max(worst[k], err)
@@ -97,8 +117,8 @@ class Shadow:
 
     def after_step(self):
         "an ordinary leapfrog step has run on the device (graph replay or eager)"
-        for p, q in zip(self.dev_params, self.params):
-            q.grad = _cpu(p.grad)
+        for q, g in zip(self.params, _cpu_all([p.grad for p in self.dev_params])):
+            q.grad = g
         self._sync_scalars(self._lr)
         self.ref.step(calc_metrics=True)
         self._check()

@@ -137,7 +137,10 @@ def test_runner_on_gpu_matches_reference_goldens(name):
     # inside _check.  Floats: N = 1024 multiplies one fp32 ulp of the potential (U ~ 60) into
     # ~8e-3 of delta_energy (inherent to the reference's formula); the
     # GPU's GEMM / reduction order differs from the CPU's, so allow a few of those.
-    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128, cfg_rtol=1e-2, cfg_atol=2e-3)
+    _check(name, metrics, runner, rtol=2e-3, atol=2e-4, de_atol=0.5, acc_atol=2.5 / 128,
+           # per-tensor configurational temperatures at model scale: the ResNet's gradient moves by per cents under
+           # one-ulp changes, and a BatchNorm scale has 16 elements to average over
+           cfg_rtol=0.1, cfg_atol=0.05)
 
 
 @pytest.mark.gpu
