@@ -71,6 +71,12 @@ class StepArgs(ctypes.Structure):
                 ("stream", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
+class FragJob(ctypes.Structure):
+    "sgmcmc_frag_job"
+    _fields_ = [("w", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("dgrad", ctypes.c_void_p),
+                ("channels", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class ReduceJob(ctypes.Structure):
     "sgmcmc_reduce_job"
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n_slabs", ctypes.c_int32),
@@ -228,6 +234,12 @@ EXPORTS = {
     "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
                                 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_sum_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2),
+    "sgmcmc_conv3x3_frag_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
+                                + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ConvBwdEpilogue)]
                                 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_bn_bwd_dx": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]

@@ -19,6 +19,7 @@ from . import bnlink as _bnlink
 
 import collections
 import contextlib
+import weakref
 
 # Layers of a GPU model that did NOT take one of this package's kernels (a shape off the tables, a switch set to 0)
 # are counted here per (operator, per-sample shape); SGMCMC_STRICT=1 turns such a library dispatch into an error --
@@ -38,6 +39,51 @@ def library_path(op, x):
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
 DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
+# the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc); 0 = the round-2 kernels, for A/B runs
+PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "1") != "0"
+
+# ---- prepared weight fragments (csrc/conv2_hip.inc) ------------------------------------------------------------
+# The persistent kernels read a convolution's weights in MFMA fragment order (forward, and transposed + flipped for
+# the data gradient).  ``frags(w)`` returns the two buffers of weight tensor w, current: inside a ``deferring(owner)``
+# scope -- ONE forward + backward evaluation, during which the weights do not change -- every weight the owner used
+# in its previous scope is prepared by ONE launch at the scope's entry; anything else is prepared by a launch of its
+# own right where it is needed (always, outside a scope: nothing is ever assumed about a weight's history).
+_frag_cache = {}      # id(weight tensor) -> [weakref, forward fragments, data-gradient fragments]
+_frag_valid = set()   # ids whose fragments are current in the active scope
+_owner_weights = {}   # id(owner) -> weak references of the weights its last scope used
+
+
+def _frag_entry(w):
+    e = _frag_cache.get(id(w))
+    if e is None or e[0]() is not w:
+        key = id(w)
+        ref = weakref.ref(w, lambda _r, key=key: _frag_cache.pop(key, None))
+        e = _frag_cache[key] = [ref, torch.empty(w.numel(), dtype=torch.float32, device=w.device),
+                                torch.empty(w.numel(), dtype=torch.float32, device=w.device)]
+    return e
+
+
+def _prepare(weights):
+    "fragments of all ``weights`` in one launch (sgmcmc_conv3x3_prepare_weights splits beyond SGMCMC_FRAG_JOBS)"
+    jobs = (_hip.FragJob * len(weights))()
+    for j, w in zip(jobs, weights):
+        e = _frag_entry(w)
+        j.w, j.fwd, j.dgrad, j.channels = w.data_ptr(), e[1].data_ptr(), e[2].data_ptr(), w.shape[0]
+    err = _hip.lib().sgmcmc_conv3x3_prepare_weights(ctypes.cast(jobs, ctypes.c_void_p), len(weights), _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_prepare_weights")
+
+
+def frags(w):
+    "(forward fragments, data-gradient fragments) of the contiguous [C, C, 3, 3] float32 weight w, current"
+    e = _frag_entry(w)
+    if id(w) not in _frag_valid:
+        _prepare([w])
+        if _defer["active"]:
+            _frag_valid.add(id(w))
+    if _defer["active"] and id(w) not in _defer["weights"]:
+        _defer["weights"][id(w)] = e[0]
+    return e[1], e[2]
 
 # ---- deferred weight-gradient reduction: opt-in, per backward pass ---------------------------------------
 # Inside ``with deferring():`` (the samplers' own gradient evaluations: potential.py, graphed.py) a
@@ -47,18 +93,27 @@ DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
 # backward (no create_graph), the weight is a leaf without a ``.grad`` yet, and the weight took part in ONE
 # forward call of this pass (a weight shared by two operations has its gradients summed mid-backward).
 # Everywhere else -- user code calling these operators directly -- the reduction is launched immediately.
-_defer = {"active": False, "uses": {}}
+_defer = {"active": False, "uses": {}, "weights": {}}
 
 
 @contextlib.contextmanager
-def deferring():
-    "scope of one forward + backward evaluation whose convolution weight gradients may be reduced at the end"
+def deferring(owner=None):
+    """scope of one forward + backward evaluation whose convolution weight gradients may be reduced at the end.
+    ``owner`` (any object, e.g. the model): the trunk weights this owner used in its previous scope get their MFMA
+    fragments prepared by one launch right here (see ``frags``)."""
     if not DEFER_REDUCE or _defer["active"]:
         yield
         return
     _defer["active"] = True
     _defer["uses"] = {}
+    _defer["weights"] = {}
+    _frag_valid.clear()
     _pending.clear()                # leftovers of a pass that raised before its final callback
+    if PERSISTENT and owner is not None:
+        known = [w for w in (r() for r in _owner_weights.get(id(owner), ())) if w is not None and w.is_cuda]
+        if known:
+            _prepare(known)
+            _frag_valid.update(id(w) for w in known)
     try:
         yield
     except BaseException:
@@ -66,8 +121,12 @@ def deferring():
         _join_side()
         raise
     finally:
+        if owner is not None:
+            _owner_weights[id(owner)] = list(_defer["weights"].values())
         _defer["active"] = False
         _defer["uses"] = {}
+        _defer["weights"] = {}
+        _frag_valid.clear()
     _flush_pending()                # no-op when the backward's final callback already ran
 
 
@@ -103,6 +162,17 @@ def _run(x, w, transpose_w, want_stats=False):
     lib = _hip.lib()
     y = torch.empty_like(x)
     stats = None
+    if PERSISTENT:
+        f_fwd, f_dgrad = frags(w)
+        if want_stats:
+            slices = lib.sgmcmc_conv3x3_frag_stat_slices(x.shape[0], x.shape[1], x.shape[2])
+            stats = torch.empty((x.shape[1], slices, 2), dtype=torch.float64, device=x.device)
+        err = lib.sgmcmc_conv3x3_frag_fwd(x.data_ptr(), (f_dgrad if transpose_w else f_fwd).data_ptr(), y.data_ptr(),
+                                          x.shape[0], x.shape[1], x.shape[2], 0 if stats is None else stats.data_ptr(),
+                                          _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv3x3_frag_fwd")
+        return y, stats
     if want_stats:   # [channels][slices][2] partial (sum, centred sum of squares) of y, for the BatchNorm that follows
         slices = lib.sgmcmc_conv3x3_stat_slices(x.shape[0], x.shape[1], x.shape[2])
         stats = torch.empty((x.shape[1], slices, 2), dtype=torch.float64, device=x.device)
@@ -140,10 +210,48 @@ def split_backward(lib, x, w, dy, dx, E, scratch, slabs):
         _hip.check(err, "sgmcmc_conv3x3_bwd_part(data)")
 
 
+def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
+    """Both gradients of y = conv3x3(x, w) by the persistent launch (sgmcmc_conv3x3_frag_bwd).  ``add`` = (e_dout,
+    e_out): dx += e_dout * [e_out > 0]; ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm
+    backward whose incoming gradient dx is.  -> (dx, dw, partial or None, n_partials); with ``defer`` dw is an alias
+    whose memory the pass's final reduction fills (one job per 16-output-channel tile)."""
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    scratch = torch.empty(lib.sgmcmc_conv3x3_frag_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
+    E = _hip.ConvBwdEpilogue()
+    if add is not None:
+        E.e_dout, E.e_out = add[0].data_ptr(), add[1].data_ptr()
+    partial, n_part = None, lib.sgmcmc_conv3x3_frag_stat_slices(n, c, hw)
+    if sums_for is not None:
+        y_bn, out_bn, saved_bn = sums_for
+        partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
+        E.s_y, E.s_out, E.s_mean, E.s_invstd = (y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(),
+                                                saved_bn[1].data_ptr())
+        E.s_partial = partial.data_ptr()
+    slabs = ctypes.c_int(0)
+    err = lib.sgmcmc_conv3x3_frag_bwd(x.data_ptr(), frags(w)[1].data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
+                                      0 if defer else dw.data_ptr(), scratch.data_ptr(), n, c, hw,
+                                      ctypes.byref(slabs) if defer else None, _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_frag_bwd")
+    if defer:
+        P, slab = slabs.value, 144 * c          # [tile][P][9][16][C]: one reduction job per output-channel tile
+        for t in range(c // 16):
+            _pending.append((scratch[t * P * slab:(t + 1) * P * slab], dw[16 * t:16 * (t + 1)], P, 9))
+        return dx, dw.view(dw.shape), partial, n_part
+    return dx, dw, partial, n_part
+
+
 def _both_grads(x, w, dy, defer, sums_for=None):
     "``sums_for`` = (y_bn, out_bn, saved_bn) of the BatchNorm + ReLU that produced x: its backward sums ride along"
     lib = _hip.lib()
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    if PERSISTENT and not (defer and SIDE_STREAM):
+        dx, dw, partial, n_part = frag_backward(lib, x, w, dy, defer, sums_for=sums_for)
+        if partial is not None:
+            _bnlink.tag_gradient(dx, partial, n_part)
+        return dx, dw
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)

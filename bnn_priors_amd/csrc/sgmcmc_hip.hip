@@ -1377,6 +1377,7 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "mlp_hip.inc"
 // the convolutional trunk's fp32-MFMA kernels (googleresnet gradient)
 #include "conv_hip.inc"
+#include "conv2_hip.inc"
 #include "conv_down_hip.inc"
 #include "conv50_hip.inc"
 #include "bn_hip.inc"

@@ -161,7 +161,7 @@ class GraphedLeapfrog(_ReportSlots):
 
     def _body(self, capturing, metrics):
         self.opt.zero_grad()
-        with _conv.deferring():
+        with _conv.deferring(self.model):
             f = self.pot._logits(self.x)
             loss = _pool.cross_entropy_backward(f, self.y)
         with torch.no_grad():
@@ -328,7 +328,7 @@ class GraphedAccumulate:
         params = self.eng.params
         for p in params:
             p.grad = None
-        with self._logging(), _conv.deferring():
+        with self._logging(), _conv.deferring(self.model):
             this = _pool.cross_entropy_backward(self.pot._logits(x), y, reduction="sum", divide_by=self.pot.N)
         got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none
         torch._foreach_add_([a for a, _ in got], [g for _, g in got])

@@ -56,7 +56,7 @@ class Potential:
             loss, log_prior, potential, accs, _ = self.model.split_potential_and_acc(x, y, self.N)
             potential.backward()
             return loss, log_prior, potential, accs.mean()
-        with _conv.deferring():      # this pass's convolution weight-gradient slabs: one reduction at its end
+        with _conv.deferring(self.model):      # this pass's convolution weight-gradient slabs: one reduction at its end
             f = self._logits(x)
             extra = self._leftover_log_prior()
             if extra is None:

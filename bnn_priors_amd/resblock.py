@@ -77,10 +77,16 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
     "y = conv3x3(x, w); out = relu(bn(y) [+ residual]) -> y, out, saved (mean, invstd)"
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     y, out = torch.empty_like(x), torch.empty_like(x)
-    slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
-    stats = torch.empty((c, slices, 2), dtype=torch.float64, device=x.device)
     saved = torch.empty((2, c), dtype=torch.float32, device=x.device)
-    err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s)
+    if _conv.PERSISTENT:
+        slices = lib.sgmcmc_conv3x3_frag_stat_slices(n, c, hw)
+        stats = torch.empty((c, slices, 2), dtype=torch.float64, device=x.device)
+        err = lib.sgmcmc_conv3x3_frag_fwd(x.data_ptr(), _conv.frags(w)[0].data_ptr(), y.data_ptr(), n, c, hw,
+                                          stats.data_ptr(), s)
+    else:
+        slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
+        stats = torch.empty((c, slices, 2), dtype=torch.float64, device=x.device)
+        err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s)
     if err:
         _hip.check(err, "sgmcmc_conv3x3")
     err = _bn.train_fwd(lib, y, residual, g, b, rm, rv, mom, eps, 1, n, c, hw * hw, out, saved, None, stats, slices, s)
@@ -181,6 +187,11 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None):
     ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward whose incoming gradient
     dx is -> (dx, dw, partial or None, n_partials)"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    if _conv.PERSISTENT and not (_conv.SIDE_STREAM and _conv._may_defer(w)):
+        defer = _conv._may_defer(w)
+        if defer:      # summed with the pass's other slabs by ONE launch at its end
+            torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
+        return _conv.frag_backward(lib, x, w, dy, defer, add=add, sums_for=sums_for)
     part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     E = _hip.ConvBwdEpilogue()

@@ -389,6 +389,7 @@ int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratc
  * slabs in `scratch` and the caller sums them later -- typically all weight gradients of a backward pass
  * in ONE launch of sgmcmc_wrw_reduce_many (same summation order: same bits). */
 #define SGMCMC_REDUCE_JOBS 32
+#define SGMCMC_FRAG_JOBS 24   /* convolutions per launch of sgmcmc_conv3x3_prepare_weights */
 typedef struct sgmcmc_reduce_job {
   const float* part; /* [n_slabs][numel] */
   float* out;        /* [numel] */
@@ -428,6 +429,35 @@ int sgmcmc_conv3x3_bwd_part(const float* x, const float* w, const float* dy, flo
                             const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
                             int which, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
+
+/* ---- the same three contractions, PERSISTENT kernels on prepared weight fragments (csrc/conv2_hip.inc; round 3) ----
+ * Replaces the convolutions of models/google_resnet.py:11-43 inside the gradient evaluation of inference.py:215-223,
+ * as sgmcmc_conv3x3 / sgmcmc_conv3x3_bwd_ex do, for the same three shapes.  Differences:
+ *   - the weights are read as MFMA fragments that sgmcmc_conv3x3_prepare_weights leaves in caller-owned buffers of
+ *     channels^2 * 9 floats each (forward order and transposed + flipped for the data gradient): ONE launch for all
+ *     convolutions of a gradient evaluation (up to SGMCMC_FRAG_JOBS per launch; more are split over launches);
+ *   - items of 4 image rows; workgroups are persistent over a stream of items, XCD-aware (an image's items, its
+ *     channel tiles and both of its gradients are processed on XCD = image mod 8);
+ *   - statistics / backward-sum partials: [channels][sgmcmc_conv3x3_frag_stat_slices(...)][2] doubles, slice =
+ *     image * (hw / 4) + band -- equal parts, as sgmcmc_bn_train_fwd / sgmcmc_bn_bwd_dx expect;
+ *   - weight-gradient slabs: `scratch` = [channels / 16][P][9][16][channels] floats, P = *deferred_slabs: one reduction
+ *     job PER 16-output-channel tile t (part = scratch + t * P * 144 * channels, out = dw + t * 144 * channels,
+ *     numel = 144 * channels, taps = 9).  With dw != NULL and deferred_slabs == NULL the reductions are launched here.
+ * Results agree with the round-2 kernels up to fp32 summation order; runs are bitwise reproducible. */
+typedef struct sgmcmc_frag_job {
+  const float* w;  /* [channels][channels][3][3] */
+  float* fwd;      /* channels^2 * 9 floats, or NULL */
+  float* dgrad;    /* channels^2 * 9 floats, or NULL */
+  int32_t channels, reserved;
+} sgmcmc_frag_job;
+int sgmcmc_conv3x3_prepare_weights(const sgmcmc_frag_job* jobs, int n_jobs, void* stream);
+int sgmcmc_conv3x3_frag_stat_slices(int n_img, int channels, int hw);
+int64_t sgmcmc_conv3x3_frag_scratch_floats(int n_img, int channels, int hw);
+int sgmcmc_conv3x3_frag_fwd(const float* x, const float* frag_fwd, float* y, int n_img, int channels, int hw,
+                            double* stats, void* stream);
+int sgmcmc_conv3x3_frag_bwd(const float* x, const float* frag_dgrad, const float* dy, float* dx,
+                            const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
+                            int hw, int* deferred_slabs, void* stream);
 
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;
  * the 1x1 shortcut's operand is the 3x3's centre tap): models/google_resnet.py:77-90.

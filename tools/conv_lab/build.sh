@@ -1,0 +1,6 @@
+#!/bin/bash
+# builds the standalone convolution lab: `lab` (timing; no stamps) and `lab_st` (wall-clock stamps inside the kernels:
+# the stamps themselves cost waits, so never time with them).  Both git-ignored; they travel with gpurun.
+cd "$(dirname "$0")"
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I ../../include -I ../../bnn_priors_amd/csrc"
+hipcc $F -DNO_STAMPS lab.hip -o lab && hipcc $F lab.hip -o lab_st
