@@ -44,6 +44,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the BASELINE configurations contain no library compute kernel in a gradient evaluation: make a silent fallback
+# (a shape off the kernel tables dispatching to MIOpen / rocBLAS) an error instead of a slower number
+os.environ.setdefault("SGMCMC_STRICT", "1")
 
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), same guide
@@ -89,6 +92,15 @@ def parse():
     ap.add_argument("--exchange-samples", type=int, default=8, help="synthetic samples per chain in the exchange leg")
     ap.add_argument("--chain-sweep", default="1,2,4,8",
                     help="densenet only: aggregate steps/s of K chains sharing ONE GPU's launches (MultiChainDense); '' = skip")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-rank run: nccl = RCCL over xGMI (the product path); gloo = "
+                         "the SAME control flow with host collectives, so that two ranks can share one GPU "
+                         "(a plumbing check of the multi-rank leg, never a scaling number)")
+    ap.add_argument("--other-workloads", type=int, default=None,
+                    help="also run BASELINE configs[1], [2], [4] (densenet, convnet, googleresnet HMC L=50 T=0.1) as "
+                         "sub-runs and report them in `other_workloads` (default: on for the default one-GPU run)")
+    ap.add_argument("--eval-rows", type=int, default=10000,
+                    help="rows of the synthetic test set of `samples_per_sec_with_eval` (CIFAR-10's test set: 10,000)")
     ap.add_argument("--stream-chains", default=None,
                     help="googleresnet / convnet: aggregate steps/s of K chains on K HIP streams of ONE GPU, e.g. '1,2,3' "
                          "(after the timed region; default: '1,2' for a one-GPU googleresnet run, '' = skip)")
@@ -255,6 +267,66 @@ def conv_rooflines(device, n_img=128, iters=60):
                              algorithmic_flops_per_launch=flops, avg_kernel_us=round(avg * 1e3, 3),
                              min_kernel_us=round(min(ms) * 1e3, 3), launches=len(ms), launches_per_step=per_step,
                              shape=dict(n=n_img, channels=c, hw=hw)))
+    return rows
+
+
+def bn_rooflines(device, n_img=128, iters=60):
+    """The trunk's BatchNorm kernels against HBM: ``bn::apply_kernel`` (normalise + [residual] + ReLU from the
+    producing convolution's statistics partials) and ``bn::bwd_dx_kernel`` (the whole BatchNorm backward given the
+    sums partials of the upstream epilogue), at the three trunk stages, launched through the C ABI with the
+    partials a convolution of the same shape leaves.  Algorithmic bytes per element: apply 8 (read y, write out;
+    12 with the residual), backward 16 (read dout, out, y; write dy).  21 + 21 launches per googleresnet step."""
+    from bnn_priors_amd import _hip, bn as _bn, conv as _conv
+    lib = _hip.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rows = []
+    for c, hw in ((16, 32), (32, 16), (64, 8)):
+        g = torch.Generator(device=device).manual_seed(100 + c)
+        x = torch.randn((n_img, c, hw, hw), generator=g, device=device)
+        w = torch.randn((c, c, 3, 3), generator=g, device=device) * (2.0 / (9 * c)) ** .5
+        res = torch.randn((n_img, c, hw, hw), generator=g, device=device)
+        dout = torch.randn((n_img, c, hw, hw), generator=g, device=device)
+        y, stats = _conv._run(x, w, False, True)
+        slices = stats.shape[1]
+        gamma, beta = torch.ones(c, device=device), torch.zeros(c, device=device)
+        rm, rv = torch.zeros(c, device=device), torch.ones(c, device=device)
+        out, dy = torch.empty_like(y), torch.empty_like(y)
+        saved = torch.empty((2, c), dtype=torch.float32, device=device)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=device)
+        elems = y.numel()
+        # the sums partials as the upstream data gradient's epilogue leaves them (same slice count as the statistics)
+        partial = torch.zeros((c, slices, 2), dtype=torch.float64, device=device)
+        n_convs = 6 if c == 16 else 5
+
+        def apply(residual):
+            _hip.check(_bn.train_fwd(lib, y, residual, gamma, beta, rm, rv, 0.1, 1e-5, 1, n_img, c, hw * hw, out, saved,
+                                     None, stats, slices, stream), "sgmcmc_bn_train_fwd")
+
+        def bwd_dx():
+            _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(),
+                                            saved[0].data_ptr(), saved[1].data_ptr(), 1, n_img, c, hw * hw,
+                                            partial.data_ptr(), slices, dy.data_ptr(), 0, dgb[0].data_ptr(),
+                                            dgb[1].data_ptr(), None, stream), "sgmcmc_bn_bwd_dx")
+        for name, fn, nbytes, per_step in (
+                (f"bn::apply_kernel<relu> {c}@{hw}^2", lambda: apply(None), 8 * elems, (n_convs + 1) // 2 + (1 if c == 16 else 0)),
+                (f"bn::apply_kernel<relu,residual> {c}@{hw}^2", lambda: apply(res), 12 * elems, n_convs // 2 + (1 if c > 16 else 0)),
+                (f"bn::bwd_dx_kernel<relu> {c}@{hw}^2", bwd_dx, 16 * elems, n_convs + 1)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(device)
+            t = PacketTimer()
+            for _ in range(iters):
+                t.arm()
+                fn()
+            ms = t.collect_ms()
+            avg = sum(ms) / len(ms)
+            gbs = nbytes / (avg * 1e-3) / 1e9
+            rows.append(dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, algorithmic_bytes_per_launch=nbytes,
+                             avg_kernel_us=round(avg * 1e3, 3), min_kernel_us=round(min(ms) * 1e3, 3),
+                             launches=len(ms), launches_per_step=per_step,
+                             regime="launch-latency bound: the tensor is cache resident and smaller than a launch's "
+                                    "fixed cost", shape=dict(n=n_img, channels=c, hw=hw)))
     return rows
 
 

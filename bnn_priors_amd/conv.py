@@ -39,8 +39,12 @@ def library_path(op, x):
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
 DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
-# the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc); 0 = the round-2 kernels, for A/B runs
-PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "1") != "0"
+# the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc).  MEASURED ALTERNATIVE, off by default: in the
+# standalone lab they are 1-13 % faster per launch than the round-2 kernels (tools/conv_lab, profiles/r03_conv_lab*),
+# inside the captured step they are not (googleresnet 1,154 -> 1,131 steps/s: cold operands of the epilogues, the
+# fragment launch, twice the slab bytes at 64 channels, twice the statistics slices for the BatchNorm kernels) --
+# DESIGN.md section 3.  SGMCMC_CONV_PERSISTENT=1 selects them (same results up to fp32 summation order: tested).
+PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "0") == "1"
 
 # ---- prepared weight fragments (csrc/conv2_hip.inc) ------------------------------------------------------------
 # The persistent kernels read a convolution's weights in MFMA fragment order (forward, and transposed + flipped for
@@ -183,9 +187,12 @@ def _run(x, w, transpose_w, want_stats=False):
     return y, stats
 
 
-def _weight_grad(x, dy):
+def _weight_grad(x, dy, w=None):
     lib = _hip.lib()
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    if PERSISTENT and w is not None:
+        # the persistent launch always carries both halves (they share the GPU): the data gradient is discarded
+        return frag_backward(lib, x, w, dy, False)[1]
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
     err = lib.sgmcmc_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), scratch.data_ptr(), n, c, hw,
@@ -374,7 +381,7 @@ class _Conv3x3(torch.autograd.Function):
             # one launch for the two of them (+ the sums of the BatchNorm that produced x, if x is tagged)
             return (*_both_grads(x, w, dy, defer, None if src_y is None else (src_y, x, src_saved)), None, None, None)
         dx = _run(dy, w, True)[0] if ctx.needs_input_grad[0] else None
-        dw = _weight_grad(x, dy) if ctx.needs_input_grad[1] else None
+        dw = _weight_grad(x, dy, w) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None, None
 
 

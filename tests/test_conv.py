@@ -36,10 +36,13 @@ def test_supported_is_false_off_the_table():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
-def test_kernels_match_float64_reference(c, hw, n):
-    "forward, data gradient, weight gradient: error of the order of MIOpen's own (fp32 summation order)"
+def test_kernels_match_float64_reference(c, hw, n, persistent, monkeypatch):
+    """forward, data gradient, weight gradient: error of the order of MIOpen's own (fp32 summation order) -- for the
+    default kernels (csrc/conv_hip.inc) and for the persistent ones on prepared weight fragments (csrc/conv2_hip.inc)"""
+    monkeypatch.setattr(conv, "PERSISTENT", persistent)
     x, w, dy = (t.cuda() for t in _data(c, hw, n))
     assert conv.supported(x, w, None, 1, 1, 1, 1) and conv.supported(x, w, None, (1, 1), (1, 1), (1, 1), 1)
     for bad in (dict(stride=2), dict(padding=0), dict(dilation=2), dict(groups=2)):
@@ -87,7 +90,7 @@ def test_gradients_are_reproducible_and_inputs_untouched():
         assert torch.equal(conv.conv3x3(x, w), outs[0][0])
     # the merged backward launch (data + weight gradient together) == the two separate entry points
     assert torch.equal(conv._run(dy, w, True)[0], outs[0][1])
-    assert torch.equal(conv._weight_grad(x, dy), outs[0][2])
+    assert torch.equal(conv._weight_grad(x, dy, w), outs[0][2])
     # accumulation into an existing .grad reads the gradient at once: that route reduces immediately
     xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
     conv.conv3x3(xg, wg).backward(dy)
@@ -200,14 +203,16 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("c,hw", SHAPES)
-def test_epilogue_statistics_feed_the_batchnorm(c, hw):
+def test_epilogue_statistics_feed_the_batchnorm(c, hw, persistent, monkeypatch):
     "conv3x3(want_stats=True): per-band sums of y; bn_train(stats=...) == bn_train() on the same y"
     from bnn_priors_amd import bn
+    monkeypatch.setattr(conv, "PERSISTENT", persistent)
     x, w, _ = (t.cuda() for t in _data(c, hw, 19))
     y, stats = conv.conv3x3(x, w, want_stats=True)
     assert torch.equal(y, conv.conv3x3(x, w))
-    _check_stats(stats, y.double(), hw // 8)          # one part per band of 8 rows
+    _check_stats(stats, y.double(), hw // (4 if persistent else 8))     # one part per band of 8 (4) rows
     g = torch.Generator().manual_seed(5)
     gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
     outs = []
