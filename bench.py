@@ -472,15 +472,16 @@ def _exchange_tables(rank, E, N, C, device):
     return lps.to(device), acc.to(device)
 
 
-def exchange_leg(model, rank, world, device, E, n_test=10000, classes=10):
+def exchange_leg(model, rank, world, device, E, cdev=None, backend="nccl", n_test=10000, classes=10):
     """Posterior-predictive ensemble over ALL chains' samples (two all-reduces, MAX and SUM, over RCCL) and
     the gather of every chain's stored samples to rank 0, on synthetic [E, N_test, C] tables / E copies of
     the model's state; the ensemble is checked on rank 0 against the single-process formula applied to the
     concatenated tables (exp_utils.py:300-321)."""
     import torch.distributed as dist
     from bnn_priors_amd.evaluation import ensemble_across_chains, gather_samples
-    lps, acc = _exchange_tables(rank, E, n_test, classes, device)
-    samples = {k: v.detach().unsqueeze(0).repeat((E,) + (1,) * v.dim()) + float(rank)
+    cdev = device if cdev is None else cdev
+    lps, acc = _exchange_tables(rank, E, n_test, classes, cdev)
+    samples = {k: (v.detach().unsqueeze(0).repeat((E,) + (1,) * v.dim()) + float(rank)).to(cdev)
                for k, v in model.state_dict().items() if v.is_floating_point()}
     ensemble_across_chains(lps, acc)                # untimed first use: RCCL sets its rings up lazily
     torch.cuda.synchronize(device)
@@ -494,7 +495,7 @@ def exchange_leg(model, rank, world, device, E, n_test=10000, classes=10):
     got = gather_samples(samples)
     torch.cuda.synchronize(device)
     t_gather = time.perf_counter() - t0
-    t = torch.tensor([t_ens, t_gather], dtype=torch.float64, device=device)
+    t = torch.tensor([t_ens, t_gather], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out = None
     if rank == 0:
@@ -508,7 +509,8 @@ def exchange_leg(model, rank, world, device, E, n_test=10000, classes=10):
         k0 = sorted(got)[0]
         ok_gather = ok_gather and all(
             bool((got[k0][r * E:(r + 1) * E] - samples[k0][0:1]).abs().max().item() == float(r)) for r in range(world))
-        out = dict(backend="nccl (RCCL)", chains=world, samples_per_chain=E, n_test=n_test, classes=classes,
+        out = dict(backend="nccl (RCCL)" if backend == "nccl" else "gloo (host collectives: a plumbing check, ranks may share a GPU)",
+                   chains=world, samples_per_chain=E, n_test=n_test, classes=classes,
                    ensemble_ms=round(t[0].item() * 1e3, 3), ensemble_max_abs_err=err,
                    ensemble_matches_single_process=bool(err < 1e-9),
                    gather_ms=round(t[1].item() * 1e3, 3), gathered_bytes_rank0=n_bytes,
@@ -516,6 +518,37 @@ def exchange_leg(model, rank, world, device, E, n_test=10000, classes=10):
                    collectives="all_reduce(MAX) + all_reduce(SUM) on [N_test, C+1] float64; all_gather per stored tensor")
         if not (out["ensemble_matches_single_process"] and ok_gather):
             raise AssertionError(f"multi-chain exchange disagrees with the single-process formula: {out}")
+    return out
+
+
+def other_workloads(args):
+    """BASELINE configs[1], [2] and [4] as sub-runs of this script (fresh processes: their own captured graphs and
+    kernel tables), so that the ONE line the driver records carries all four GPU configurations.  Each sub-run times
+    its leapfrog loop exactly as the headline does and K = 10 full sample cycles; no rooflines, no CPU baseline."""
+    import subprocess
+    subs = {
+        "configs[1] densenet VerletSGLDReject": ["--workload", "densenet", "--chain-sweep", ""],
+        "configs[2] convnet VerletSGLDReject laplace": ["--workload", "convnet"],
+        "configs[4] googleresnet HMCReject L=50 T=0.1 student-t": ["--inference", "HMCReject", "--trajectory", "50",
+                                                                  "--temperature", "0.1"],
+    }
+    out = {}
+    for name, flags in subs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "100", "--warmup", "20",
+               "--cpu-budget", "0", "--sweep-log2", "0", "--no-kernel-timing", "--stream-chains", "", "--samples", "10",
+               "--other-workloads", "0", "--eval-rows", "0", "--metrics-skip", str(args.metrics_skip)] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            sps = line.get("samples_per_sec") or {}
+            out[name] = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                         "samples_per_sec": sps.get("value"), "leapfrog_steps_per_sample": sps.get("leapfrog_steps_per_sample"),
+                         "workload": line["config"]["workload"], "step_path": line["config"]["step_path"],
+                         "timed_steps": line["timing"]["timed_steps"], "sub_run_s": round(time.perf_counter() - t0, 1)}
+        except Exception as exc:      # a sub-run never takes the headline down
+            out[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
     return out
 
 
@@ -543,14 +576,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
-    device = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and args.backend != "gloo":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {n_dev} GPU(s) visible (ranks may share a GPU only with "
+                         "--backend gloo: RCCL needs one device per rank)")
+    device = torch.device("cuda", local % n_dev)
     torch.cuda.set_device(device)
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     pinned_cpus = None
     if distributed:   # one process per GPU under torch.distributed.run; "nccl" is RCCL on ROCm
         import torch.distributed as dist
         pinned_cpus = pin_process(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    # where the control-flow collectives' tensors live: RCCL moves device memory, gloo host memory
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
 
     from bnn_priors_amd.inference_reject import runner_class
     from bnn_priors_amd.storage import MemoryMetrics
@@ -620,7 +662,7 @@ def main():
     torch.cuda.synchronize(device)
     n_blocks = max(1, min(args.max_blocks, math.ceil(args.min_seconds / max(time.perf_counter() - t0, 1e-6))))
     if distributed:
-        nb = torch.tensor([n_blocks], device=device)
+        nb = torch.tensor([n_blocks], device=cdev)
         dist.broadcast(nb, src=0)
         n_blocks = int(nb.item())
         dist.barrier()
@@ -641,7 +683,7 @@ def main():
     block_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
     med_ms = statistics.median(block_ms)
     if distributed:
-        t = torch.tensor([med_ms, wall], device=device, dtype=torch.float64)
+        t = torch.tensor([med_ms, wall], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         med_ms, wall = t[0].item(), t[1].item()
     dt_block = med_ms * 1e-3
@@ -660,49 +702,69 @@ def main():
         for _ in range(200):
             opt.step(calc_metrics=False)
         ktimes = eng.stop_kernel_timing()
-    samples = None
+    samples = samples_noreject = samples_eval = None
     if args.samples > 0:
-        # one stored sample = L leapfrog steps + the exact full-data gradient + final_step + M-H test
-        # + initial_step (inference_reject.py:86-157); timed end to end, K times
+        # one stored sample = L leapfrog steps + the runner's own M-H point (inference_reject.py:115-157: exact
+        # full-data gradient, final_step, energy difference, M-H test, metrics row, momentum refresh for HMC,
+        # initial_step) -- timed end to end, K times, through the SAME method the runner's loop calls
         all_b = list(pool.index_batches()) if fused else list(pool)
         rows_all = [torch.arange(128 * b, min(128 * (b + 1), N), device=device) for b in range(len(all_b))]
-        opt = runner.optimizer
 
-        def one_sample(step, reject=runner.reject_samples):
+        def one_sample(step, save=None):
+            acc = 0.0
             for i, (x, y) in enumerate(all_b):
                 step += 1
                 if augment is not None:
                     x = augment.gather(pool.x, rows_all[i], step // len(all_b))
-                runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
-            step += 1
-            loss, log_prior, potential = runner._exact_model_potential_and_grad(pool)
-            opt.final_step(calc_metrics=True)
-            de = runner._delta_energy(potential)
-            de = de.item() if isinstance(de, torch.Tensor) else de
-            runner._initial_potential = potential.item()
-            if reject:
-                opt.maybe_reject(de)
-            runner.scheduler.step()
-            if hmc:
-                opt.sample_momentum()
-            opt.initial_step(calc_metrics=False, save_state=reject)
-            return step
+                acc = runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
+            runner._drain_rows()
+            return runner._mh_point(step, acc, pool, save=save)
 
-        def timed_samples(reject):
-            s = one_sample(step, reject)          # untimed: first use of this variant's launches
+        def timed_samples(save=None):
+            s = one_sample(step, save)          # untimed: first use of this variant's launches
             torch.cuda.synchronize(device)
             ts = time.perf_counter()
             for _ in range(args.samples):
-                s = one_sample(s, reject)
+                s = one_sample(s, save)
             torch.cuda.synchronize(device)
             return args.samples / (time.perf_counter() - ts), s
 
-        samples, step = timed_samples(runner.reject_samples)
+        samples, step = timed_samples()
         # the paper's default, reject_samples=False: no state snapshot at initial_step, no M-H test
-        samples_noreject = None
         if runner.reject_samples:
-            samples_noreject, step = timed_samples(False)
-    exchange = exchange_leg(model, rank, world, device, args.exchange_samples) if distributed else None
+            runner.reject_samples = False
+            samples_noreject, step = timed_samples()
+            runner.reject_samples = True
+        # ... and what the reference's sample cycle also contains (inference_reject.py:142-144): the posterior-
+        # predictive evaluation of the new sample over the test set and the sample written to the HDF5 store
+        if args.eval_rows > 0 and rank == 0:
+            import tempfile
+            from bnn_priors_amd import _h5, storage
+            g = torch.Generator(device=device).manual_seed(99)
+            xt = (torch.randn if args.workload == "googleresnet" else torch.rand)((args.eval_rows,) + xshape, generator=g, device=device)
+            yt = torch.randint(0, 10, (args.eval_rows,), generator=g, device=device)
+            runner.dataloader_test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xt, yt), batch_size=128)
+            tmp = tempfile.mkdtemp(prefix="sgmcmc_bench_")
+            runner.model_saver = (storage.HDF5ModelSaver(os.path.join(tmp, "samples.h5"), "w").__enter__()
+                                  if _h5.available() else storage.MemoryModelSaver())
+            store = type(runner.model_saver).__name__
+            t_eval0 = time.perf_counter()
+            runner._evaluate_model(runner.model.state_dict(), step)
+            torch.cuda.synchronize(device)
+            t_eval = time.perf_counter() - t_eval0          # (first call: includes any warm-up)
+            rate, step = timed_samples(save=(0, runner.epochs_per_cycle - 1))
+            t_eval0 = time.perf_counter()
+            runner._evaluate_model(runner.model.state_dict(), step)
+            torch.cuda.synchronize(device)
+            samples_eval = dict(per_chain=round(rate, 3), test_rows=args.eval_rows, store=store,
+                                evaluate_model_ms=round((time.perf_counter() - t_eval0) * 1e3, 2),
+                                first_evaluate_model_ms=round(t_eval * 1e3, 2))
+            if hasattr(runner.model_saver, "__exit__"):
+                runner.model_saver.__exit__(None, None, None)
+            runner.dataloader_test, runner.model_saver = empty_test, None
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    exchange = exchange_leg(model, rank, world, device, args.exchange_samples, cdev, args.backend) if distributed else None
 
     value = world * K / dt_block
     out = {
@@ -716,7 +778,9 @@ def main():
                                + (" augment=crop(pad 4)+flip on device" if augment is not None else "")
                                + (f" trajectory={args.trajectory}" if hmc and args.trajectory else ""),
                    "params": n_params, "tensors": len(list(model.parameters())),
-                   "chains": world, "parallelism": f"{world} independent chain(s), one per GPU",
+                   "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"
+                   if args.backend == "nccl" else
+                   f"{world} ranks over gloo, sharing GPUs: a plumbing check of the multi-rank leg, NOT a scaling number",
                    "step_path": path},
         "timing": {"blocks": n_blocks, "steps_per_block": K, "timed_steps": n_blocks * K,
                    "median_block_ms": round(med_ms, 4), "min_block_ms": round(min(block_ms), 4),
@@ -734,8 +798,14 @@ def main():
                                   "leapfrog_steps_per_sample": L, "reject_samples": runner.reject_samples,
                                   "per_chain_reject_samples_false":
                                       None if samples_noreject is None else round(samples_noreject, 3),
-                                  "includes": "L leapfrog steps, exact full-data gradient pass "
-                                              "(N rows), final_step, M-H test, initial_step"}
+                                  "includes": "L leapfrog steps, then the runner's own M-H point (_mh_point): exact "
+                                              "full-data gradient pass (N rows), final_step, M-H test, metrics row, "
+                                              "initial_step"}
+        if samples_eval is not None:
+            out["samples_per_sec_with_eval"] = dict(
+                samples_eval, value=round(world * samples_eval["per_chain"], 3),
+                includes="the same cycle + _evaluate_model over a synthetic test set (model.eval(), E = 1) + "
+                         "_save_sample into the sample store, as inference_reject.py:142-144")
     if exchange is not None:
         out["exchange"] = exchange
     if rank == 0:
@@ -758,10 +828,17 @@ def main():
             # the step is dominated by the trunk's convolution gradients (profiles/): the headline roofline is
             # the kernel with the largest share of the step, the sampler's HBM line is reported beside it
             convs = conv_rooflines(device)
-            top = max(convs, key=lambda r: r["avg_kernel_us"] * r["launches_per_step"])
-            out["roofline"] = dict(top, share_note="dominant kernel = largest (launches per step x duration) among "
-                                                   "the step's kernels")
-            out["roofline_kernels"] = convs
+            try:
+                bns = bn_rooflines(device)
+            except Exception as exc:       # (an extra table: never takes the bench line down)
+                bns = []
+                out["roofline_bn_error"] = f"{type(exc).__name__}: {exc}"
+            rows_all_k = convs + bns
+            top = max(rows_all_k, key=lambda r: r["avg_kernel_us"] * r["launches_per_step"])
+            out["roofline"] = dict(top, share_note="dominant kernel = largest (launches per step x duration) over ALL "
+                                                   "rows of roofline_kernels (convolutions against the fp32-MFMA peak, "
+                                                   "BatchNorm kernels against HBM)")
+            out["roofline_kernels"] = rows_all_k
             if sampler_line:
                 out["roofline_sampler"] = sampler_line
         elif sampler_line:
@@ -780,6 +857,12 @@ def main():
                     method="K runners, each with its own captured step on its own HIP stream (no augmentation gather)")
             except Exception as exc:       # an extension after the timed region: never takes the bench line down
                 out["chains_per_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
+        other = args.other_workloads
+        if other is None:
+            other = int(world == 1 and args.workload == "googleresnet" and args.inference == "VerletSGLDReject"
+                        and not args.eager)
+        if other:
+            out["other_workloads"] = other_workloads(args)
         if world == 1 and args.cpu_budget > 0:
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]

@@ -243,6 +243,33 @@ static void run_shape(int n_img, int n_wg) {
   }
   chain("v1 bwd+sums", b1);
   chain("v2 bwd+sums", b2);
+  {
+    // the same launches on ROTATING operand sets (R sets x 4 tensors: far more than the 8 x 4 MB of L2), so that every
+    // launch finds its operands where a step's kernel finds them -- in the Infinity Cache / HBM, not in its XCD's L2
+    const int R = (int)std::max<size_t>(3, (size_t)(160u << 20) / (4 * act * sizeof(float)));
+    std::vector<float*> xs(R), dys(R), outs(R), ys(R);
+    for (int r = 0; r < R; ++r) {
+      xs[r] = dalloc(act); dys[r] = dalloc(act); outs[r] = dalloc(act); ys[r] = dalloc(act);
+      CK(hipMemcpy(xs[r], x, act * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(dys[r], dy, act * 4, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy(outs[r], out, act * 4, hipMemcpyDeviceToDevice));
+    }
+    int k = 0;
+    printf("  -- rotating over %d operand sets (%.0f MB): L2-cold launches\n", R, R * 4.0 * act * 4 / 1e6);
+    chain("v1 fwd+stats, cold", [&] { k = (k + 1) % R; conv::launch_conv3x3<C, HW, 8>(xs[k], w, ys[k], n_img, false, st1, s); });
+    chain("v2 fwd+stats, cold", [&] { k = (k + 1) % R; SGMCMC_LAUNCH(k2, dim3(n_wg), dim3(256), G2::LDS_BYTES, s, xs[k], ffwd, ys[k], st2, n_img); });
+    chain("v1 bwd+sums, cold", [&] { k = (k + 1) % R; conv::BwdEpilogue E = E1; E.s_y = xs[k]; E.s_out = outs[k];
+                                      conv::launch_bwd<C, HW, 8>(xs[k], w, dys[k], ys[k], dw1, part1, n_img, &slabs, s, E); });
+    chain("v2 bwd+sums, cold", [&] { k = (k + 1) % R; conv::BwdEpilogue E = E2; E.s_y = xs[k]; E.s_out = outs[k];
+                                      SGMCMC_LAUNCH(kb, dim3(n_wg), dim3(256), lds2, s, xs[k], fdg, dys[k], ys[k], part2, n_wrw, n_img, E); });
+    conv::BwdEpilogue Ea1 = E1, Ea2 = E2;
+    auto kba = conv2::bwd_kernel<C, HW, R2, true, true>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kba), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    chain("v1 bwd+add+sums, cold", [&] { k = (k + 1) % R; conv::BwdEpilogue E = Ea1; E.s_y = xs[k]; E.s_out = outs[k]; E.e_dout = dys[(k + 1) % R]; E.e_out = outs[(k + 1) % R];
+                                          conv::launch_bwd<C, HW, 8>(xs[k], w, dys[k], ys[k], dw1, part1, n_img, &slabs, s, E); });
+    chain("v2 bwd+add+sums, cold", [&] { k = (k + 1) % R; conv::BwdEpilogue E = Ea2; E.s_y = xs[k]; E.s_out = outs[k]; E.e_dout = dys[(k + 1) % R]; E.e_out = outs[(k + 1) % R];
+                                          SGMCMC_LAUNCH(kba, dim3(n_wg), dim3(256), lds2, s, xs[k], fdg, dys[k], ys[k], part2, n_wrw, n_img, E); });
+    for (int r = 0; r < R; ++r) { CK(hipFree(xs[r])); CK(hipFree(dys[r])); CK(hipFree(outs[r])); CK(hipFree(ys[r])); }
+  }
   timeit("v1 bwd+sums", b1);
   timeit("v2 bwd+sums (256 wrw + 256 dgrad)", b2);
   // the halves alone
