@@ -234,6 +234,8 @@ EXPORTS = {
     "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
                                 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_sum_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_bn_eval_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] + [ctypes.c_int] * 4
+                           + [ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
     "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),

@@ -30,6 +30,29 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def eval_supported(x, weight, bias, running_mean, running_var):
+    "evaluation mode (running statistics) without a graph: the per-epoch test pass and the stored samples' predictions"
+    return (ENABLED and not torch.is_grad_enabled() and weight is not None and bias is not None
+            and running_mean is not None and running_var is not None and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and x.shape[0] > 0 and (x.shape[2] * x.shape[3]) % 4 == 0
+            and weight.dtype == torch.float32 and not torch._C._functorch.is_batchedtensor(weight))
+
+
+def bn_eval(x, weight, bias, running_mean, running_var, eps, residual=None, relu=False):
+    "relu?(batch_norm(x; running statistics) [+ residual]) in one launch (sgmcmc_bn_eval_fwd)"
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    y = torch.empty_like(x)
+    n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+    err = _hip.lib().sgmcmc_bn_eval_fwd(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(),
+                                        running_mean.data_ptr(), running_var.data_ptr(), float(eps), int(bool(relu)), n, c,
+                                        plane, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if err:
+        _hip.check(err, "sgmcmc_bn_eval_fwd")
+    return y
+
+
 # ---- running statistics logged instead of updated ---------------------------------------------------------------
 # Inside ``with logging_running_stats(slots):`` (slots: id(running_mean tensor) -> float64 [C, 2] device tensor) a
 # training-mode forward leaves its batch mean / unbiased variance in the layer's slot and does NOT touch the running

@@ -19,6 +19,7 @@ from . import bnlink as _bnlink
 
 import collections
 import contextlib
+import warnings
 import weakref
 
 # Layers of a GPU model that did NOT take one of this package's kernels (a shape off the tables, a switch set to 0)
@@ -30,10 +31,17 @@ LIBRARY_CALLS = collections.Counter()
 
 def library_path(op, x):
     if x.is_cuda and torch.is_grad_enabled():      # (gradient evaluations only: evaluation passes are not the hot path)
-        LIBRARY_CALLS[(op, tuple(x.shape[1:]))] += 1
+        key = (op, tuple(x.shape[1:]))
+        first = key not in LIBRARY_CALLS
+        LIBRARY_CALLS[key] += 1
         if STRICT:
             raise RuntimeError(f"SGMCMC_STRICT=1: {op} on a per-sample shape {tuple(x.shape[1:])} has no kernel in "
                                "bnn_priors_amd and would run on the library path (MIOpen / rocBLAS / ATen)")
+        if first:       # loud, once per (operator, shape): a width / depth off the kernel tables is several times slower
+            warnings.warn(f"bnn_priors_amd: {op} on a per-sample shape {tuple(x.shape[1:])} has no hand-written kernel and "
+                          "runs on the library path (MIOpen / rocBLAS / ATen) inside a gradient evaluation; kernel "
+                          "tables: conv.SHAPES, conv.DOWN_SHAPES, the 50-channel classifier -- set SGMCMC_STRICT=1 to "
+                          "make this an error", RuntimeWarning, stacklevel=3)
 
 
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)

@@ -214,6 +214,10 @@ class _BatchNorm2d(nn.BatchNorm2d):
         if self.track_running_stats and _bn.supported(x, self.weight, self.bias, self.training, self.momentum):
             return _bn.bn_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                 self.momentum, self.eps, residual, relu, stats)
+        if (not self.training and self.track_running_stats
+                and _bn.eval_supported(x, self.weight, self.bias, self.running_mean, self.running_var)):
+            # evaluation passes (inference.py:199-213): running statistics, residual add and ReLU in one launch
+            return _bn.bn_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, residual, relu)
         if self.training:
             if _bn.log_active():
                 raise _bn.LogModeUnsupported("a BatchNorm layer on the library path cannot log its batch statistics")

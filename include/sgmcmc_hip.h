@@ -523,6 +523,11 @@ int sgmcmc_conv50_bwd(const float* x, const float* w, const float* dy, float* dx
  * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane) doubles of per-slice partial sums, combined in
  * a fixed order (deterministic).  Forward: when `stats_in` ([channels][stats_slices][2] partial (sum, sum of squared
  * deviations from the partial's own mean) of x over EQUAL parts, e.g. from sgmcmc_conv3x3) is given, the statistics pass over x is skipped. */
+/* Evaluation mode (model.eval(): the per-epoch posterior-predictive evaluation of inference.py:199-213): one pass with
+ * the running statistics, y = relu?(gamma (x - running_mean) / sqrt(running_var + eps) + beta [+ residual]). */
+int sgmcmc_bn_eval_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, double eps, int relu, int n,
+                       int channels, int plane, float* y, void* stream);
 int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane);
 int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, double momentum, double eps, int relu,

@@ -128,3 +128,59 @@ def test_statistics_do_not_cancel_against_the_mean(offset):
     ref = (xd - xd.mean(dim=(0, 2, 3), keepdim=True)) / (xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()
     # the input itself carries offset * 2^-24 of rounding: that, not the statistics, bounds the agreement
     torch.testing.assert_close(y.double(), ref, rtol=0, atol=1e-4 + 4 * offset * 2.0 ** -24 / 0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw,n", [(16, 32, 128), (32, 16, 5), (64, 8, 1)])
+@pytest.mark.parametrize("relu,with_residual", [(True, False), (True, True), (False, False)])
+def test_eval_mode_batchnorm_kernel_matches_aten(c, hw, n, relu, with_residual):
+    "model.eval(): running statistics + residual + ReLU in one launch == F.batch_norm(training=False) (+ add, relu)"
+    from bnn_priors_amd import bn
+    g = torch.Generator().manual_seed(c + n)
+    x = (torch.randn(n, c, hw, hw, generator=g) * 2 + 0.5).cuda()
+    res = torch.randn(n, c, hw, hw, generator=g).cuda() if with_residual else None
+    w, b = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    rm, rv = torch.randn(c, generator=g).cuda(), (torch.rand(c, generator=g) + 0.1).cuda()
+    with torch.no_grad():
+        assert bn.eval_supported(x, w, b, rm, rv)
+        got = bn.bn_eval(x, w, b, rm, rv, 1e-5, res, relu)
+        ref = torch.nn.functional.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5)
+        if res is not None:
+            ref = ref + res
+        if relu:
+            ref = torch.relu(ref)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    assert not bn.eval_supported(x, w, b, rm, rv)            # with grad mode on: the differentiable library operator
+
+
+@pytest.mark.gpu
+def test_eval_mode_forward_of_the_resnet_runs_on_this_packages_kernels():
+    """the per-epoch evaluation pass (inference.py:199-213): same logits as the library path, and no ATen batch_norm /
+    MIOpen convolution in it"""
+    from bnn_priors_amd import bn, conv, models, pool, resblock
+    torch.manual_seed(0)
+    x = torch.randn(64, 3, 32, 32).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    models.he_initialize(net)
+    net.train()
+    with torch.no_grad():
+        net.net(x)                       # running statistics away from their initial values
+    net.eval()
+    with torch.no_grad():
+        got = net.net(x)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            net.net(x)
+        names = {e.key for e in prof.key_averages()}
+        assert not any("batch_norm" in k or "convolution" in k for k in names), sorted(names)
+        mods = (bn, conv, pool, resblock)
+        old = [m.ENABLED for m in mods]
+        try:
+            for m in mods:
+                m.ENABLED = False
+            ref = net.net(x)
+        finally:
+            for m, v in zip(mods, old):
+                m.ENABLED = v
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)

@@ -459,8 +459,13 @@ def test_baseline_conv_models_take_no_library_path_in_a_gradient_evaluation(name
     torch.cuda.synchronize()
     # what an off-table layer would do: counted (and refused under SGMCMC_STRICT=1) -- without running the library here
     odd = torch.empty(4, 3, 24, 24, device="cuda")
-    conv.library_path("conv2d", odd)
-    assert conv.LIBRARY_CALLS == {("conv2d", (3, 24, 24)): 1}
+    with pytest.warns(RuntimeWarning, match="library path"):      # loud, once per (operator, shape)
+        conv.library_path("conv2d", odd)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        conv.library_path("conv2d", odd)                             # ... the second time only counted
+    assert conv.LIBRARY_CALLS == {("conv2d", (3, 24, 24)): 2}
     conv.LIBRARY_CALLS.clear()
     old = conv.STRICT
     conv.STRICT = True
