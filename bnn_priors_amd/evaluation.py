@@ -183,14 +183,29 @@ def predictive_tables(model, dataloader_test, samples):
     lps = torch.zeros((E, N), dtype=torch.float64, device=device)
     acc = torch.zeros((E, N, C), dtype=torch.float64, device=device)
     kind = None
-    graphed = isinstance(model, ClassificationModel) and device.type == "cuda" and not model.training
+    graphed = (isinstance(model, ClassificationModel) and device.type == "cuda" and not model.training
+               and labels.dim() == 1)
+    plain_temp = graphed and isinstance(model.softmax_temp, (int, float))
     for e in range(E):
         model.load_state_dict({k: v[e] for k, v in samples.items()})
         i = 0
         for bx, by in dataloader_test:
             bx, by = bx.to(device), by.to(device)
-            # (same arithmetic as ``model(bx)``: likelihood_dist(net(x)); the forward itself replayed from a graph)
-            preds = model.likelihood_dist(_logits_fn(model, bx)) if graphed else model(bx)
+            if graphed and plain_temp:
+                # the numbers ``model(bx)`` = Categorical(logits=net(x) / T) would hold -- normalised logits and
+                # log p(y|x) -- without building the distribution object (its argument validation synchronises
+                # with the host once per batch); the forward itself is replayed from a captured graph
+                f = _logits_fn(model, bx)
+                f = f if model.softmax_temp == 1 else f / model.softmax_temp
+                a = f - f.logsumexp(dim=-1, keepdim=True)          # torch/distributions/categorical.py: logits
+                lp = a.gather(-1, by.view(-1, 1)).squeeze(-1)
+                kind = "cat"
+                j = i + len(bx)
+                lps[e, i:j] = lp
+                acc[e, i:j] = a
+                i = j
+                continue
+            preds = model(bx)
             if isinstance(preds, torch.distributions.Categorical):
                 kind, a, lp = "cat", preds.logits, preds.log_prob(by)
             elif isinstance(preds, torch.distributions.Normal):

@@ -162,8 +162,9 @@ class GraphedLeapfrog(_ReportSlots):
     def _body(self, capturing, metrics):
         self.opt.zero_grad()
         with _conv.deferring(self.model):
-            f = self.pot._logits(self.x)
-            loss = _pool.cross_entropy_backward(f, self.y)
+            with _pool.head_loss(self.y):
+                f = self.pot._logits(self.x)
+            loss = _pool.cross_entropy_backward(f, self.y, want_loss=metrics)
         with torch.no_grad():
             self.opt._prepare_hyper_grads()
         self.eng.refresh(self.opt._preconditioners(), defer_upload=capturing)
@@ -171,7 +172,7 @@ class GraphedLeapfrog(_ReportSlots):
             self.eng.prior_grad(self.pot.N, metrics)
         self.eng.step_indirect(self._A_host[metrics], self.args_dev.data_ptr())
         if not metrics:
-            return loss.detach(), None
+            return None if loss is None else loss.detach(), None
         with torch.no_grad():
             acc = f.argmax(dim=1).eq(self.y).double().mean()
             packed = torch.cat([loss.detach().double().view(1), acc.view(1), self.eng.scalars[:4],
@@ -329,7 +330,9 @@ class GraphedAccumulate:
         for p in params:
             p.grad = None
         with self._logging(), _conv.deferring(self.model):
-            this = _pool.cross_entropy_backward(self.pot._logits(x), y, reduction="sum", divide_by=self.pot.N)
+            with _pool.head_loss(y, "sum", self.pot.N):
+                f = self.pot._logits(x)
+            this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.pot.N)
         got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none
         torch._foreach_add_([a for a, _ in got], [g for _, g in got])
         self.loss += this.detach().double()

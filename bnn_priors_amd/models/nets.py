@@ -247,8 +247,29 @@ def _conv_bn(conv, bn, x, residual=None, relu=False):
 class _BNTrunk(nn.Sequential):
     "a Sequential that advances the batch counters of its ``_BatchNorm2d`` layers once per forward"
 
+    def _flat_counters(self):
+        """the BatchNorm layers' ``num_batches_tracked`` as 0-dim views of ONE int64 array, so that the head's launch
+        (or one ATen launch) advances all of them; rebuilt whenever a layer's buffer is not such a view any more
+        (``.to()``, ``deepcopy``, a re-registered buffer)"""
+        bns = [m for m in self.modules() if isinstance(m, _BatchNorm2d) and m.track_running_stats
+               and m.momentum is not None]
+        if not bns:
+            return None
+        flat = self.__dict__.get("_bn_flat")
+        if (flat is None or flat.numel() != len(bns) or flat.device != bns[0].num_batches_tracked.device
+                or any(m.num_batches_tracked.data_ptr() != flat.data_ptr() + 8 * i for i, m in enumerate(bns))):
+            with torch.no_grad():
+                flat = torch.stack([m.num_batches_tracked.detach().reshape(()).to(torch.int64) for m in bns]).contiguous()
+                for i, m in enumerate(bns):
+                    m.num_batches_tracked = flat[i]
+            self.__dict__["_bn_flat"] = flat
+        return flat
+
     def forward(self, x):
         out, mods, i = x, list(self), 0
+        # (log mode: the caller advances the counters afterwards)
+        counters = self._flat_counters() if (self.training and not _bn.log_active()) else None
+        counted = counters is None
         while i < len(mods):
             m = mods[i]
             if (isinstance(m, Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], _BatchNorm2d)
@@ -261,19 +282,13 @@ class _BNTrunk(nn.Sequential):
                   and _all_of(m.kernel_size, out.shape[2:]) and m.padding in (0, (0, 0))
                   and _pool.head_supported(out, mods[i + 2].weight, mods[i + 2].bias)):
                 lin = mods[i + 2]                                 # global average pool + linear head
-                out, i = _pool.pool_linear(out, lin.weight, lin.bias), i + 3
+                out, i = _pool.pool_linear(out, lin.weight, lin.bias, None if counted else counters), i + 3
+                counted = True
             else:
                 out, i = m(out), i + 1
-        if self.training and not _bn.log_active():       # (log mode: the caller advances the counters afterwards)
-            counters = self.__dict__.get("_bn_counters")
-            if counters is None or any(c is not m.num_batches_tracked for c, m in counters):
-                counters = [(m.num_batches_tracked, m) for m in self.modules()
-                            if isinstance(m, _BatchNorm2d) and m.track_running_stats
-                            and m.momentum is not None]
-                self.__dict__["_bn_counters"] = counters
-            if counters:
-                with torch.no_grad():
-                    torch._foreach_add_([c for c, _ in counters], 1)
+        if not counted:
+            with torch.no_grad():
+                counters.add_(1)
         return out
 
 

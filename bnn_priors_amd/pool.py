@@ -3,6 +3,7 @@ backward (``csrc/pool_hip.inc``; C ABI ``sgmcmc_bias_relu_pool_fwd/_bwd``): what
 convolution of bnn_priors/models/conv_nets.py:44-56.  The convolution then runs without its bias; the
 bias gradient comes out of the same backward pass (per-block partials, fixed-order reduction).
 """
+import contextlib
 import os
 
 import torch
@@ -100,14 +101,80 @@ def _reduce_rows(slabs, out, defer):
     return out
 
 
+# ---- head + loss + both backward passes in one launch (csrc/pool_hip.inc, head::loss_kernel) ----------------------
+# A caller that is about to take ``cross_entropy_backward(model.net(x), y, ...)`` announces the labels first:
+#
+#     with pool.head_loss(y, reduction, divide_by):
+#         f = model.net(x)
+#     loss = pool.cross_entropy_backward(f, y, reduction, divide_by)
+#
+# A trunk that ends in the fused head (``pool_linear``) then computes, in the head's ONE launch, the logits, the loss
+# rows, d loss / d logits and the head's whole backward (dh, the rows of dW / db, the last BatchNorm's backward sums) --
+# everything between the last activation and its gradient is per image.  ``cross_entropy_backward`` recognises the
+# tagged logits and seeds autograd with the stashed gradient; ``_PoolLinear.backward`` hands out what the launch
+# already produced.  Three launches at the launch floor become one; any other use of the logits (another loss, a
+# temperature, other labels) takes the separate kernels as before.
+FUSED_HEAD = os.environ.get("SGMCMC_FUSED_HEAD", "1") != "0"
+_head = {"spec": None, "last": None, "counted": False}
+
+
+@contextlib.contextmanager
+def head_loss(y, reduction="mean", divide_by=None):
+    old = _head["spec"]
+    _head["spec"] = (y, reduction, divide_by)
+    try:
+        yield
+    finally:
+        _head["spec"] = old
+
+
+def _grad_scale(rows, reduction, divide_by):
+    "(scale of the loss, scale of d loss / d logits) as cross_entropy_backward forms them (float32 arithmetic)"
+    import numpy as np
+    scale = 1.0 / rows if reduction == "mean" else 1.0
+    seed = np.float32(1.0) if divide_by is None else np.float32(1.0) / np.float32(divide_by)
+    return scale, float(seed * np.float32(scale))
+
+
 class _PoolLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, bias, src_y=None, src_saved=None):
+    def forward(ctx, h, weight, bias, src_y=None, src_saved=None, counters=None):
         _conv._note_use(*((weight,) if bias is None else (weight, bias)))
         h, weight = h.contiguous(), weight.contiguous()
         n, c, plane, k = h.shape[0], h.shape[1], h.shape[2] * h.shape[3], weight.shape[0]
         pooled = torch.empty((n, c), dtype=torch.float32, device=h.device)
         logits = torch.empty((n, k), dtype=torch.float32, device=h.device)
+        ctx.fused = None
+        _head["last"], _head["counted"] = None, False
+        spec = _head["spec"]
+        if (FUSED_HEAD and spec is not None and ctx.needs_input_grad[0] and n <= 1024 and spec[0].is_cuda
+                and spec[0].dtype == torch.int64 and spec[0].dim() == 1 and spec[0].shape[0] == n
+                and spec[1] in ("mean", "sum")):
+            y, reduction, divide_by = spec
+            y = y.contiguous()
+            dev = h.device
+            want_w, want_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+            d = torch.empty((n, k), dtype=torch.float32, device=dev)
+            loss_rows = torch.empty((n,), dtype=torch.float32, device=dev)
+            dh = torch.empty_like(h)
+            sw = torch.empty((n, k * c), dtype=torch.float32, device=dev) if want_w else None
+            sb = torch.empty((n, k), dtype=torch.float32, device=dev) if want_b else None
+            partial = torch.empty((c, n, 2), dtype=torch.float64, device=dev) if src_y is not None else None
+            _, gscale = _grad_scale(n, reduction, divide_by)
+            p = lambda t: 0 if t is None else t.data_ptr()
+            err = _hip.lib().sgmcmc_pool_linear_loss(
+                h.data_ptr(), weight.data_ptr(), p(bias), y.data_ptr(), pooled.data_ptr(), logits.data_ptr(), d.data_ptr(),
+                loss_rows.data_ptr(), dh.data_ptr(), p(sw), p(sb), p(src_y), h.data_ptr() if src_y is not None else 0,
+                p(src_saved[0]) if src_y is not None else 0, p(src_saved[1]) if src_y is not None else 0, p(partial),
+                p(counters), 0 if counters is None else counters.numel(), n, c, plane, k, gscale, _conv._stream())
+            if err:
+                _hip.check(err, "sgmcmc_pool_linear_loss")
+            ctx.fused = (d, dh, sw, sb, partial)
+            _head["last"] = (spec, d, loss_rows)
+            _head["counted"] = counters is not None
+            ctx.save_for_backward(pooled, weight, bias, src_y, src_saved, h if src_y is not None else None)
+            ctx.h_shape = tuple(h.shape)
+            return logits
         err = _hip.lib().sgmcmc_pool_linear_fwd(h.data_ptr(), weight.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                                 pooled.data_ptr(), logits.data_ptr(), n, c, plane, k, _conv._stream())
         if err:
@@ -120,6 +187,16 @@ class _PoolLinear(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dlogits):
         pooled, weight, bias, src_y, src_saved, h = ctx.saved_tensors
+        if ctx.fused is not None and dlogits.data_ptr() == ctx.fused[0].data_ptr():
+            # the gradient the forward launch already propagated (head_loss): nothing left to launch
+            _, dh, sw, sb, partial = ctx.fused
+            ctx.fused = None
+            if partial is not None:
+                _bnlink.tag_gradient(dh, partial, ctx.h_shape[0])
+            dw = _reduce_rows(sw, torch.empty_like(weight), _conv._may_defer(weight)) if sw is not None else None
+            db = _reduce_rows(sb, torch.empty_like(bias), _conv._may_defer(bias)) if sb is not None else None
+            return dh, dw, db, None, None, None
+        ctx.fused = None
         dlogits = dlogits.contiguous()
         n, c, hh, ww = ctx.h_shape
         k = weight.shape[0]
@@ -146,15 +223,25 @@ class _PoolLinear(torch.autograd.Function):
             dw = _reduce_rows(sw, torch.empty_like(weight), _conv._may_defer(weight))
         if want_b:
             db = _reduce_rows(sb, torch.empty_like(bias), _conv._may_defer(bias))
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None
 
 
-def pool_linear(h, weight, bias=None):
-    "linear(h.mean(dim=(2, 3)), weight, bias) for NCHW float32 h with <= 64 channels and <= 16 outputs"
+def pool_linear(h, weight, bias=None, counters=None):
+    """linear(h.mean(dim=(2, 3)), weight, bias) for NCHW float32 h with <= 64 channels and <= 16 outputs.
+    ``counters``: a contiguous int64 tensor that gets + 1 along the way (the trunk's BatchNorm batch counters) --
+    inside the head's launch when it is the fused one (``head_loss``), by one ATen launch otherwise."""
     src_y, src_saved = (None, None)
     if h.requires_grad and h.shape[2] * h.shape[3] == 64:
         src_y, src_saved = _bnlink.source_of(h)
-    return _PoolLinear.apply(h, weight, bias, src_y, src_saved)
+    logits = _PoolLinear.apply(h, weight, bias, src_y, src_saved, counters)
+    if _head["last"] is not None:
+        logits._sgmcmc_head_loss = _head["last"] + (logits._version,)
+        _head["last"] = None
+    if counters is not None and not _head["counted"]:
+        with torch.no_grad():
+            counters.add_(1)
+    _head["counted"] = False
+    return logits
 
 
 # ------------------------------------------------------------------ narrow linear layer
@@ -244,13 +331,25 @@ class _SoftmaxXent(torch.autograd.Function):
         return d, None, None
 
 
-def cross_entropy_backward(logits, y, reduction="mean", divide_by=None):
+def cross_entropy_backward(logits, y, reduction="mean", divide_by=None, want_loss=True):
     """``loss = F.cross_entropy(logits, y, reduction=...) [/ divide_by]; loss.backward()`` with the likelihood's
     forward and backward in ONE launch: the kernel leaves the loss and d loss / d logits, and autograd is seeded
     with the latter (``logits.backward(dlogits)``).  Same bits as ``cross_entropy(...)`` followed by
-    ``backward()``.  Returns the detached loss."""
+    ``backward()``.  Returns the detached loss (None with ``want_loss=False``: a captured step that logs nothing does
+    not spend a launch on summing the loss rows of the fused head)."""
     if reduction not in ("mean", "sum"):
         raise ValueError("reduction must be 'mean' or 'sum'")
+    st = getattr(logits, "_sgmcmc_head_loss", None)
+    if st is not None:
+        (sy, sred, sdiv), d, loss_rows, version = st
+        if sy is y and sred == reduction and sdiv == divide_by and logits._version == version and logits.requires_grad:
+            # the head's launch already holds d loss / d logits and everything behind it (``head_loss``)
+            logits.backward(d)
+            if not want_loss:
+                return None
+            scale, _ = _grad_scale(logits.shape[0], reduction, divide_by)
+            loss = loss_rows.sum() * scale
+            return loss if divide_by is None else loss / divide_by
     if not (xent_supported(logits, y) and logits.requires_grad):
         loss = cross_entropy(logits, y, reduction)
         if divide_by is not None:

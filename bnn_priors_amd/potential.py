@@ -57,11 +57,13 @@ class Potential:
             potential.backward()
             return loss, log_prior, potential, accs.mean()
         with _conv.deferring(self.model):      # this pass's convolution weight-gradient slabs: one reduction at its end
-            f = self._logits(x)
             extra = self._leftover_log_prior()
             if extra is None:
+                with _pool.head_loss(y):                        # a fused head also takes the loss and both backward passes
+                    f = self._logits(x)
                 loss = _pool.cross_entropy_backward(f, y)       # likelihood forward + backward seed: one launch
             else:
+                f = self._logits(x)
                 loss = _pool.cross_entropy(f, y)
                 (loss - extra / self.N).backward()
         self.opt.add_prior_gradient(calc_log_prior=want_metrics)
@@ -126,7 +128,9 @@ class Potential:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:
                 # (gradients accumulate into existing .grad tensors here, so nothing is deferred)
-                this = _pool.cross_entropy_backward(self._logits(x), y, reduction="sum", divide_by=self.N)
+                with _pool.head_loss(y, "sum", self.N):
+                    f = self._logits(x)
+                this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.N)
                 loss = loss + this.double()
         if acc is not None:
             acc.finish()

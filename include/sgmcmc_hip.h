@@ -586,6 +586,18 @@ int sgmcmc_pool_linear_fwd(const float* h, const float* weight, const float* bia
 int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const float* weight, float* dh,
                            float* slab_w, float* slab_b, int n, int channels, int plane, int classes,
                            void* stream);
+/* The head, the softmax cross-entropy on its logits and both backward passes in ONE launch (round 3): everything
+ * between the trunk's last activation h and its gradient dh is per image.  Outputs: pooled / logits as
+ * sgmcmc_pool_linear_fwd, loss_rows[n] = -log softmax(logits_n)[y_n], dlogits = grad_scale * (softmax - onehot) -- the
+ * bits of sgmcmc_softmax_xent_fwd_grad -- and dh / slab_w / slab_b (/ partial, with the four bn_* pointers: plane == 64)
+ * as sgmcmc_pool_linear_bwd[_sums] would produce from that dlogits.  counters (may be NULL): n_counters <= 256 int64
+ * values that get + 1 (the BatchNorm layers' num_batches_tracked, kept in one array).  Replaces the head's Linear,
+ * Categorical(logits).log_prob and their autograd backward inside R1 (inference.py:215-223, models/base.py:168-191). */
+int sgmcmc_pool_linear_loss(const float* h, const float* weight, const float* bias, const int64_t* y, float* pooled,
+                            float* logits, float* dlogits, float* loss_rows, float* dh, float* slab_w, float* slab_b,
+                            const float* bn_y, const float* bn_out, const float* bn_mean, const float* bn_invstd,
+                            double* partial, int64_t* counters, int n_counters, int n, int channels, int plane,
+                            int classes, float grad_scale, void* stream);
 /* ... when h is the output of a BatchNorm + ReLU (bn_y its input, bn_out = h, saved mean / invstd) on 8x8 maps
  * (plane == 64): the launch also leaves that BatchNorm's backward sums, partial[(c * n + image) * 2 + {0,1}] doubles
  * (n slices per channel) for sgmcmc_bn_bwd_dx -- the last BatchNorm of models/google_resnet.py:103-110's trunk. */

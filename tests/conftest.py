@@ -28,3 +28,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """the CPU sides of the parity tests (oracle samplers, eager torch-CPU forward / backward of the nets) are many small
+    operators: on a 256-core GPU host torch's default of one thread per core makes them several times SLOWER"""
+    import torch
+    if (os.cpu_count() or 1) > 16:
+        torch.set_num_threads(16)
+    yield

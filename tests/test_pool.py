@@ -187,3 +187,42 @@ def test_narrow_linear_matches_float64(n, j, k, with_bias):
         torch.testing.assert_close(bg.grad.double().cpu(), br.grad, rtol=1e-5, atol=2e-6 * n ** .5)
     y2 = pool.linear(xg, wg, bg)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,reduction,divide_by", [(128, "mean", None), (80, "sum", 50000.0), (3, "mean", None)])
+def test_fused_head_loss_launch_equals_the_three_separate_kernels(n, reduction, divide_by, monkeypatch):
+    """head_loss: logits, loss rows, d loss / d logits and the head's whole backward in ONE launch -- the same bits as
+    pool_linear forward + softmax cross-entropy (fwd + seed) + pool_linear backward, counters advanced on the way"""
+    from bnn_priors_amd import pool
+    g = torch.Generator().manual_seed(n)
+    h0 = torch.randn(n, 64, 8, 8, generator=g).cuda()
+    W0, b0 = (torch.randn(10, 64, generator=g) * 0.2).cuda(), torch.randn(10, generator=g).cuda()
+    y = torch.randint(0, 10, (n,), generator=g).cuda()
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(pool, "FUSED_HEAD", fused)
+        h, W, b = h0.clone().requires_grad_(), W0.clone().requires_grad_(), b0.clone().requires_grad_()
+        counters = torch.arange(21, dtype=torch.int64).cuda()
+        with pool.head_loss(y, reduction, divide_by):
+            f = pool.pool_linear(h, W, b, counters)
+        assert hasattr(f, "_sgmcmc_head_loss") == fused
+        loss = pool.cross_entropy_backward(f, y, reduction, divide_by)
+        assert torch.equal(counters.cpu(), torch.arange(21) + 1)
+        outs.append((f.detach(), loss.detach(), h.grad, W.grad, b.grad))
+    for a, b_, name in zip(outs[0], outs[1], ("logits", "loss", "dh", "dW", "db")):
+        if name == "loss":          # the rows are summed by another (ATen) reduction: last-ulp differences
+            torch.testing.assert_close(a, b_, rtol=1e-6, atol=0)
+        else:
+            assert torch.equal(a, b_), name
+    # other labels / another reduction than announced: the tagged logits are not used
+    monkeypatch.setattr(pool, "FUSED_HEAD", True)
+    h, W = h0.clone().requires_grad_(), W0.clone().requires_grad_()
+    with pool.head_loss(y, reduction, divide_by):
+        f = pool.pool_linear(h, W, None)
+    y2 = (y + 1) % 10
+    pool.cross_entropy_backward(f, y2, "mean")
+    h2, W2 = h0.clone().requires_grad_(), W0.clone().requires_grad_()
+    torch.nn.functional.cross_entropy(torch.nn.functional.linear(h2.mean(dim=(2, 3)), W2), y2).backward()
+    torch.testing.assert_close(h.grad, h2.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(W.grad, W2.grad, rtol=1e-4, atol=1e-6)
