@@ -254,6 +254,9 @@ EXPORTS = {
     "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
                               + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv50": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv50_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv50_bwd_t": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                                   ctypes.c_void_p]),
     "sgmcmc_conv50_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
     "sgmcmc_conv50_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                                  ctypes.c_void_p]),

@@ -618,10 +618,14 @@ class _Conv50(torch.autograd.Function):
         _note_use(w)
         x, w = x.contiguous(), w.contiguous()
         y = torch.empty_like(x)
-        err = _hip.lib().sgmcmc_conv50(x.data_ptr(), w.data_ptr(), y.data_ptr(), x.shape[0], 0, _stream())
+        # the forward launch also leaves the weights as the data gradient reads them (transposed, taps flipped)
+        wT = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        err = _hip.lib().sgmcmc_conv50_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0 if wT is None else wT.data_ptr(),
+                                           x.shape[0], _stream())
         if err:
-            _hip.check(err, "sgmcmc_conv50")
+            _hip.check(err, "sgmcmc_conv50_fwd")
         ctx.save_for_backward(x, w)
+        ctx.wT = wT
         return y
 
     @staticmethod
@@ -629,11 +633,15 @@ class _Conv50(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _hip.lib()
         x, w = ctx.saved_tensors
+        wT = ctx.wT
         dy = dy.contiguous()
         n = x.shape[0]
         if not ctx.needs_input_grad[1]:
             dx = torch.empty_like(x)
-            err = lib.sgmcmc_conv50(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, 1, _stream())
+            if wT is not None:
+                err = lib.sgmcmc_conv50_fwd(dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), 0, n, _stream())
+            else:
+                err = lib.sgmcmc_conv50(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, 1, _stream())
             if err:
                 _hip.check(err, "sgmcmc_conv50")
             return dx, None
@@ -644,9 +652,13 @@ class _Conv50(torch.autograd.Function):
         slabs = ctypes.c_int(0)
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
-        err = lib.sgmcmc_conv50_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0 if dx is None else dx.data_ptr(),
-                                    dw.data_ptr(), scratch.data_ptr(), n, ctypes.byref(slabs) if defer else None,
-                                    _stream())
+        if dx is not None and wT is not None:
+            err = lib.sgmcmc_conv50_bwd_t(x.data_ptr(), wT.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                          scratch.data_ptr(), n, ctypes.byref(slabs) if defer else None, _stream())
+        else:
+            err = lib.sgmcmc_conv50_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0 if dx is None else dx.data_ptr(),
+                                        dw.data_ptr(), scratch.data_ptr(), n, ctypes.byref(slabs) if defer else None,
+                                        _stream())
         if err:
             _hip.check(err, "sgmcmc_conv50_bwd")
         if defer:

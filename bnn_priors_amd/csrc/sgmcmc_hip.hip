@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sgmcmc_hip.h"
 

@@ -511,6 +511,13 @@ int sgmcmc_conv50(const float* x, const float* w, float* y, int n_img, int trans
 int64_t sgmcmc_conv50_scratch_floats(int n_img);
 int sgmcmc_conv50_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* scratch, int n_img,
                       int* deferred_slabs, void* stream);
+/* Round 3: the forward also leaves wT[ci][co][rs] = w[co][ci][8 - rs] (2500 * 9 floats; NULL: not wanted) -- the weights
+ * as the data gradient's rows -- so that the backward stages them with the forward's straight copy instead of strided
+ * gathers: sgmcmc_conv50_bwd_t(x, wT, dy, dx (required), dw, scratch, ...) = sgmcmc_conv50_bwd with w replaced by the
+ * wT of a forward on the SAME weights; a data gradient alone is sgmcmc_conv50_fwd(dy, wT, dx, NULL, ...). */
+int sgmcmc_conv50_fwd(const float* x, const float* w, float* y, float* wT, int n_img, void* stream);
+int sgmcmc_conv50_bwd_t(const float* x, const float* wT, const float* dy, float* dx, float* dw, float* scratch,
+                        int n_img, int* deferred_slabs, void* stream);
 
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
