@@ -217,6 +217,7 @@ EXPORTS = {
     "sgmcmc_pool_slices": (ctypes.c_int, [ctypes.c_int] * 4),
     "sgmcmc_bias_relu_pool_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_bias_relu_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "sgmcmc_linear_fwd_loss": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]),
     "sgmcmc_pool_linear_loss": (ctypes.c_int, [ctypes.c_void_p] * 17 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
     "sgmcmc_pool_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 11 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

@@ -258,7 +258,27 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         _conv._note_use(weight)
         x, weight = x.contiguous(), weight.contiguous()
-        y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+        n, k = x.shape[0], weight.shape[0]
+        y = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        spec = _head["spec"]
+        _head["last"] = None
+        if (FUSED_HEAD and spec is not None and n <= 1024 and spec[0].is_cuda and spec[0].dtype == torch.int64
+                and spec[0].dim() == 1 and spec[0].shape[0] == n and spec[1] in ("mean", "sum")
+                and any(ctx.needs_input_grad)):
+            # ``head_loss``: the likelihood's forward + seed in the last layer's launch (the backward stays lin::bwd)
+            lab, reduction, divide_by = spec
+            d = torch.empty_like(y)
+            loss_rows = torch.empty((n,), dtype=torch.float32, device=x.device)
+            _, gscale = _grad_scale(n, reduction, divide_by)
+            err = _hip.lib().sgmcmc_linear_fwd_loss(x.data_ptr(), weight.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                    lab.contiguous().data_ptr(), y.data_ptr(), d.data_ptr(),
+                                                    loss_rows.data_ptr(), n, x.shape[1], k, gscale, _conv._stream())
+            if err:
+                _hip.check(err, "sgmcmc_linear_fwd_loss")
+            _head["last"] = (spec, d, loss_rows)
+            ctx.save_for_backward(x, weight)
+            ctx.has_bias = bias is not None
+            return y
         err = _hip.lib().sgmcmc_linear_fwd(x.data_ptr(), weight.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                            y.data_ptr(), x.shape[0], x.shape[1], weight.shape[0], _conv._stream())
         if err:
@@ -293,7 +313,11 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, weight, bias=None):
     "F.linear(x, weight, bias) for 2-D float32 x and at most 16 output features"
-    return _Linear.apply(x, weight, bias)
+    y = _Linear.apply(x, weight, bias)
+    if _head["last"] is not None:          # (``head_loss`` was active: the launch also produced the likelihood's seed)
+        y._sgmcmc_head_loss = _head["last"] + (y._version,)
+        _head["last"] = None
+    return y
 
 
 # ------------------------------------------------------------------ softmax cross-entropy

@@ -647,6 +647,12 @@ int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scra
  * batch rows, for sgmcmc_wrw_reduce_many (fixed order). */
 int sgmcmc_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int n, int in_features,
                       int out_features, void* stream);
+/* sgmcmc_linear_fwd and, in the same launch, the rows' softmax cross-entropy on the logits it produced: dlogits =
+ * grad_scale * (softmax(y_n) - onehot(y_labels[n])) and loss_rows[n] = -log softmax(y_n)[y_labels[n]] -- the bits of
+ * sgmcmc_softmax_xent_fwd_grad (models/conv_nets.py:57-70 + models/base.py:168-191 in one launch). */
+int sgmcmc_linear_fwd_loss(const float* x, const float* weight, const float* bias, const int64_t* y_labels, float* y,
+                           float* dlogits, float* loss_rows, int n, int in_features, int out_features,
+                           float grad_scale, void* stream);
 int sgmcmc_linear_row_groups(int n);
 int sgmcmc_linear_bwd(const float* x, const float* weight, const float* dy, float* dx, float* dweight_slabs,
                       float* dbias, int n, int in_features, int out_features, void* stream);

@@ -226,3 +226,28 @@ def test_fused_head_loss_launch_equals_the_three_separate_kernels(n, reduction, 
     torch.nn.functional.cross_entropy(torch.nn.functional.linear(h2.mean(dim=(2, 3)), W2), y2).backward()
     torch.testing.assert_close(h.grad, h2.grad, rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(W.grad, W2.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,reduction,divide_by", [(128, "mean", None), (96, "sum", 60000.0)])
+def test_fused_linear_forward_and_loss_equals_the_two_kernels(n, reduction, divide_by, monkeypatch):
+    "the convolutional classifier's head: linear forward + softmax cross-entropy seed in one launch, same bits"
+    from bnn_priors_amd import pool
+    g = torch.Generator().manual_seed(n)
+    x0 = torch.randn(n, 2450, generator=g).cuda()
+    W0, b0 = (torch.randn(10, 2450, generator=g) * 0.02).cuda(), torch.randn(10, generator=g).cuda()
+    y = torch.randint(0, 10, (n,), generator=g).cuda()
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(pool, "FUSED_HEAD", fused)
+        x, W, b = x0.clone().requires_grad_(), W0.clone().requires_grad_(), b0.clone().requires_grad_()
+        with pool.head_loss(y, reduction, divide_by):
+            f = pool.linear(x, W, b)
+        assert hasattr(f, "_sgmcmc_head_loss") == fused
+        loss = pool.cross_entropy_backward(f, y, reduction, divide_by)
+        outs.append((f.detach(), loss.detach(), x.grad, W.grad, b.grad))
+    for a, b_, name in zip(outs[0], outs[1], ("logits", "loss", "dx", "dW", "db")):
+        if name == "loss":
+            torch.testing.assert_close(a, b_, rtol=1e-6, atol=0)
+        else:
+            assert torch.equal(a, b_), name
