@@ -864,9 +864,16 @@ def main():
         if other:
             out["other_workloads"] = other_workloads(args)
         if world == 1 and args.cpu_budget > 0:
+            from oracle import nets as oracle_nets
             from oracle.runner import time_cpu_baseline
             cpu_batches = [(x.cpu(), y.cpu()) for x, y in list(pool)[:16]]
-            res = time_cpu_baseline(lambda: make_model(args.workload, "cpu", prior), cpu_batches,
+
+            def make_cpu_model():      # the oracle's own plain-torch restatement of the net: nothing of the product
+                torch.manual_seed(0)
+                m = oracle_nets.BUILDERS[name](weight_prior=prior)
+                oracle_nets.he_initialize(m)
+                return m
+            res = time_cpu_baseline(make_cpu_model, cpu_batches,
                                     num_data=float(N), lr=0.01, momentum=0.994, temperature=1.0,
                                     steps_per_cycle=L * 50, budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
@@ -874,7 +881,8 @@ def main():
                 "kind": "port", "host_cpus": res["host_cpus"],
                 "threads_calibration_steps_per_s": res["calibration"],
                 "sample": f"{res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
-                          "(oracle/: reference-op-order torch-CPU loop, per-tensor sampler)"}
+                          "(oracle/: reference-op-order torch-CPU loop on oracle/nets.py's plain-torch restatement of "
+                          "the net, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

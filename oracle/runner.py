@@ -36,8 +36,16 @@ def cpu_leapfrog(model, opt, scheduler, x, y, step, num_data, grad_max=1e6, metr
     return dict(potential=potential, delta_energy=de)     # (tensors: no extra read-back in the timed loop)
 
 
+def get_cosine_schedule(samples_per_cycle):
+    "lr multiplier of step i: 0.5 (cos(pi (i mod S) / S) + 1)  (bnn_priors/utils.py:5-10)"
+    import math
+
+    def schedule(i):
+        return 0.5 * (math.cos(math.pi * ((i % samples_per_cycle) / samples_per_cycle)) + 1.)
+    return schedule
+
+
 def _setup(make_model, batches, num_data, lr, momentum, temperature, steps_per_cycle):
-    from bnn_priors_amd.schedule import get_cosine_schedule  # a pure function of i (utils.py:5-10)
     model = make_model()
     opt = RefVerletSGLD(list(model.parameters()), lr=lr, num_data=num_data, momentum=momentum,
                         temperature=temperature)

@@ -1,8 +1,8 @@
 """Pins ``oracle/runner.py::cpu_leapfrog`` -- the loop ``bench.py`` times as ``cpu_baseline`` -- to the
 reference's own loop body (bnn_priors/inference_reject.py:86-113, inference.py:215-223):
 
-* ``test_cpu_leapfrog_matches_reference_fixture`` (runs everywhere): K steps of ``cpu_leapfrog`` on the
-  product's CPU model reproduce the parameter vector / potentials / delta_energy that the IMPORTED REFERENCE
+* ``test_cpu_leapfrog_matches_reference_fixture`` (runs everywhere): K steps of ``cpu_leapfrog`` on the oracle's own
+  plain-torch network (oracle/nets.py; a reference-shaped model only supplies the initial values) reproduce the parameter vector / potentials / delta_energy that the IMPORTED REFERENCE
   produced for the same inputs and torch seed (tests/golden/cpu_loop.npz, make_cpu_loop_golden.py);
 * ``test_cpu_leapfrog_matches_imported_reference`` (needs /root/reference): the same comparison live,
   statement for statement, bit for bit.
@@ -75,10 +75,13 @@ def reference_loop(model, batches, k, *, num_data, lr, momentum, temperature, st
 
 
 def oracle_loop(model, batches, k, *, num_data, lr, momentum, temperature, steps_per_cycle, metrics_skip, seed):
-    "the same K steps through oracle/runner.py (the thing bench.py times)"
-    from bnn_priors_amd.schedule import get_cosine_schedule
+    """the same K steps through oracle/runner.py ON oracle/nets.py's restatement of the network (the thing bench.py
+    times): ``model`` only supplies the initial parameter values"""
+    from oracle import nets as N
     from oracle import runner as R
+    from oracle.runner import get_cosine_schedule
     from oracle.samplers import RefVerletSGLD
+    model = N.load_parameters(N.densenet(), model)
     torch.manual_seed(seed)
     opt = RefVerletSGLD(list(model.parameters()), lr=lr, num_data=num_data, momentum=momentum,
                         temperature=temperature)
@@ -140,3 +143,26 @@ def test_cpu_leapfrog_matches_imported_reference():
     assert np.array_equal(t_ref, t_own)                     # bit for bit: identical op sequence
     assert p_ref == p_own
     np.testing.assert_allclose(d_own, d_ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name,xshape,prior", [("classificationdensenet", (784,), "gaussian"),
+                                               ("classificationconvnet", (784,), "laplace"),
+                                               ("googleresnet", (3, 32, 32), "student-t")])
+def test_oracle_nets_agree_with_the_reference_shaped_models(name, xshape, prior):
+    """oracle/nets.py against the models whose goldens are pinned to the reference (same state, CPU): identical
+    parameter lists, and loss / log-prior / potential / accuracy of one batch equal to fp32 rounding"""
+    from bnn_priors_amd import models
+    from oracle import nets as N
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn((16,) + xshape, generator=g), torch.randint(0, 10, (16,), generator=g)
+    torch.manual_seed(0)
+    ref = models.get_model(x[:2], torch.tensor([0, 9]), name, width=50, depth=3, weight_prior=prior,
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
+    models.he_initialize(ref)
+    own = N.load_parameters(N.BUILDERS[name](weight_prior=prior), ref)
+    # (the reference-shaped models keep nn.DataParallel's "module." level in their names; the oracle's do not)
+    assert [n for n, _ in own.named_parameters()] == [n.replace("net.module.", "net.") for n, _ in ref.named_parameters()]
+    a = ref.split_potential_and_acc(x, y, 50000.)
+    b = own.split_potential_and_acc(x, y, 50000.)
+    for u, v, what in zip(a[:4], b[:4], ("loss", "log_prior", "potential", "acc")):
+        torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6, msg=what)
