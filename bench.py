@@ -737,7 +737,7 @@ def main():
             runner.reject_samples = True
         # ... and what the reference's sample cycle also contains (inference_reject.py:142-144): the posterior-
         # predictive evaluation of the new sample over the test set and the sample written to the HDF5 store
-        if args.eval_rows > 0 and rank == 0:
+        if args.eval_rows > 0 and world == 1:      # (one process: a rank that evaluates would keep the others waiting in the exchange)
             import tempfile
             from bnn_priors_amd import _h5, storage
             g = torch.Generator(device=device).manual_seed(99)
