@@ -99,6 +99,10 @@ def parse():
     ap.add_argument("--other-workloads", type=int, default=None,
                     help="also run BASELINE configs[1], [2], [4] (densenet, convnet, googleresnet HMC L=50 T=0.1) as "
                          "sub-runs and report them in `other_workloads` (default: on for the default one-GPU run)")
+    ap.add_argument("--width", type=int, default=50,
+                    help="hidden width of densenet / convnet (experiments/train_bnn.py:53-54 makes it a user option; the "
+                         "BASELINE configs use 50).  Widths off the kernel tables run on the library path: needs "
+                         "SGMCMC_STRICT=0 in the environment, and the line says so in config.step_path")
     ap.add_argument("--eval-rows", type=int, default=10000,
                     help="rows of the synthetic test set of `samples_per_sec_with_eval` (CIFAR-10's test set: 10,000)")
     ap.add_argument("--stream-chains", default=None,
@@ -138,13 +142,13 @@ class PoolSource:
             yield IndexBatch(idx, self.x, self.y), None
 
 
-def make_model(workload, device, prior=None):
+def make_model(workload, device, prior=None, width=50):
     from bnn_priors_amd import models
     name, xshape, _, default_prior = WORKLOADS[workload]
     prior = prior or default_prior
     torch.manual_seed(0)
     x0 = torch.zeros((2,) + xshape)
-    net = models.get_model(x0, torch.tensor([0, 9]), name, width=50, depth=3, weight_prior=prior,
+    net = models.get_model(x0, torch.tensor([0, 9]), name, width=width, depth=3, weight_prior=prior,
                            weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.)
     models.he_initialize(net)
     return net.to(device)
@@ -552,6 +556,11 @@ def other_workloads(args):
     return out
 
 
+def _library_calls():
+    from bnn_priors_amd import conv
+    return {f"{op}{list(shape)}": n for (op, shape), n in conv.LIBRARY_CALLS.items()}
+
+
 def pin_process(local, local_world):
     "one rank = one contiguous share of the host's CPUs (8 drivers + 8 HIP runtimes must not migrate / collide)"
     try:
@@ -605,7 +614,7 @@ def main():
     prior = args.weight_prior or prior
     L = -(-N // 128)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
-    model = make_model(args.workload, device, prior)
+    model = make_model(args.workload, device, prior, args.width)
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
     n_params = sum(p.numel() for p in model.parameters())
@@ -781,7 +790,8 @@ def main():
                    "chains": world, "parallelism": f"{world} independent chain(s), one per GPU"
                    if args.backend == "nccl" else
                    f"{world} ranks over gloo, sharing GPUs: a plumbing check of the multi-rank leg, NOT a scaling number",
-                   "step_path": path},
+                   "step_path": path + (f" [width {args.width}: off the kernel tables, library calls in the step: "
+                                        f"{_library_calls()}]" if args.width != 50 else "")},
         "timing": {"blocks": n_blocks, "steps_per_block": K, "timed_steps": n_blocks * K,
                    "median_block_ms": round(med_ms, 4), "min_block_ms": round(min(block_ms), 4),
                    "max_block_ms": round(max(block_ms), 4), "region_wall_s": round(wall, 4),

@@ -176,6 +176,7 @@ class _ConvPoolTrunk(nn.Sequential):
                 elif _conv.conv50_supported(x, w, None, *m.conv_args):
                     y = _conv.conv50(x, w)
                 else:
+                    _conv.library_path("conv2d", x)         # counted, announced once per shape, an error when strict
                     y = nn.functional.conv2d(x, w, None, *m.conv_args)
                 b = m.bias
                 if _pool.supported(y, b):

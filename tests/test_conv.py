@@ -477,3 +477,18 @@ def test_baseline_conv_models_take_no_library_path_in_a_gradient_evaluation(name
     finally:
         conv.STRICT = old
         conv.LIBRARY_CALLS.clear()
+
+
+@pytest.mark.gpu
+def test_a_convnet_width_off_the_tables_is_loud_not_silent():
+    "width != 50 (experiments/train_bnn.py:53-54 makes it an option): MIOpen runs the convolutions -- announced, counted"
+    from bnn_priors_amd import models
+    torch.manual_seed(0)
+    x, y = torch.rand(8, 784).cuda(), (torch.arange(8) % 10).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "classificationconvnet", width=64, depth=3,
+                           weight_prior="laplace", weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    conv.LIBRARY_CALLS.clear()
+    with pytest.warns(RuntimeWarning, match="library path"):
+        F.cross_entropy(net.net(x), y).backward()
+    assert {k[0] for k in conv.LIBRARY_CALLS} == {"conv2d"} and len(conv.LIBRARY_CALLS) == 2, dict(conv.LIBRARY_CALLS)
+    conv.LIBRARY_CALLS.clear()
