@@ -20,6 +20,8 @@ import warnings
 
 import torch
 
+from . import _capture
+
 __all__ = ("evaluate_model", "predictive_tables", "ensemble_across_chains", "ensemble_metrics",
            "gather_samples")
 
@@ -133,7 +135,7 @@ class _GraphedLogits:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _capture.capture(self.graph):
             self.out = model.net(self.x)
 
     def __call__(self, x):

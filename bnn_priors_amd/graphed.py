@@ -31,7 +31,7 @@ from . import bn as _bn
 from . import conv as _conv
 from . import pool as _pool
 
-from . import _hip
+from . import _capture, _hip
 
 
 def _stageable(dst, src):
@@ -218,7 +218,7 @@ class GraphedLeapfrog(_ReportSlots):
         for metrics in (False, True):
             self.opt.zero_grad()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture.capture(g):
                 self.outputs[metrics] = self._body(True, metrics)
             self.graphs[metrics] = g
             self.static_grads[metrics] = [p.grad for p in self.eng.params]
@@ -312,7 +312,7 @@ class GraphedAccumulate:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _capture.capture(self.graph):
             self._body()
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
