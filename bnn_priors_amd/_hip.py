@@ -265,6 +265,14 @@ EXPORTS = {
     "sgmcmc_conv_first_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
     "sgmcmc_conv_first_wrw": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                                       ctypes.c_void_p]),
+    "sgmcmc_conv50_pool_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv50_pool_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv50_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int,
+                                                                       ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv_first_pool_fwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv_first_pool_scratch_floats": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv_first_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int,
+                                                                           ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_softmax_xent_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                                         ctypes.c_void_p]),
     "sgmcmc_softmax_xent_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double,

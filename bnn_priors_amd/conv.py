@@ -603,6 +603,69 @@ def conv_first(x, w):
     return _ConvFirst.apply(x, w)
 
 
+# ---- the first layer with its tail (csrc/conv_down_hip.inc, convfirst::fwd_pool_kernel / wrw_pool_kernel) -----------
+# SGMCMC_CONV_POOL=0 restores conv -> bias_relu_pool as two operators (A/B runs, and the tests' cross-check).
+CONV_POOL = os.environ.get("SGMCMC_CONV_POOL", "1") != "0"
+
+
+def first_pool_supported(x, w, bias, stride, padding, dilation, groups):
+    "``first_supported`` + a float32 bias (or none) for the fused conv -> + bias -> ReLU -> MaxPool2d(2)"
+    return (CONV_POOL and first_supported(x, w, None, stride, padding, dilation, groups)
+            and (bias is None or (bias.dtype == torch.float32 and tuple(bias.shape) == (50,) and bias.is_cuda)))
+
+
+class _ConvFirstPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _note_use(w) if bias is None else _note_use(w, bias)
+        x, w = x.contiguous(), w.contiguous()
+        n = x.shape[0]
+        pooled = torch.empty((n, 50, 14, 14), dtype=torch.float32, device=x.device)
+        code = torch.empty((n, 50, 14, 14), dtype=torch.uint8, device=x.device)
+        err = _hip.lib().sgmcmc_conv_first_pool_fwd(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                    pooled.data_ptr(), code.data_ptr(), n, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_first_pool_fwd")
+        ctx.save_for_backward(x, w, bias, code)
+        return pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dpooled):
+        lib = _hip.lib()
+        x, w, bias, code = ctx.saved_tensors
+        want_w, want_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        if not (want_w or want_b):
+            return None, None, None
+        dpooled = dpooled.contiguous()
+        n = x.shape[0]
+        scratch = torch.empty(lib.sgmcmc_conv_first_pool_scratch_floats(n), dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(bias) if want_b else None
+        defer = _may_defer(w) and (not want_b or _may_defer(bias))
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv_first_pool_bwd(x.data_ptr(), dpooled.data_ptr(), code.data_ptr(), dw.data_ptr(),
+                                             0 if db is None else db.data_ptr(), scratch.data_ptr(), n, int(want_b),
+                                             ctypes.byref(slabs) if defer else None, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv_first_pool_bwd")
+        if defer:
+            P = slabs.value
+            _pending.append((scratch[:P * 450], dw, P, 1))
+            if want_b:
+                _pending.append((scratch[P * 450:], db, P, 1))
+                return None, dw.view(dw.shape), db.view(db.shape)
+            return None, dw.view(dw.shape), None
+        return None, dw, db
+
+
+def conv_first_pool(x, w, bias=None):
+    "max_pool2d(relu(conv2d(x, w, bias, padding=1)), 2) for x [N, 1, 28, 28] (no gradient), w [50, 1, 3, 3]"
+    return _ConvFirstPool.apply(x, w, bias)
+
+
 # ------------------------------------------------------------------ the convolutional classifier's second layer
 def conv50_supported(x, w, bias, stride, padding, dilation, groups):
     "50 -> 50 channels, 3x3 / stride 1 / pad 1 on 14x14 maps (csrc/conv50_hip.inc); the bias joins the fused tail"
@@ -670,3 +733,68 @@ class _Conv50(torch.autograd.Function):
 def conv50(x, w):
     "conv2d(x, w, padding=1) for x [N, 50, 14, 14], w [50, 50, 3, 3]"
     return _Conv50.apply(x, w)
+
+
+# ---- ... and the second layer with its tail (csrc/conv50_hip.inc, conv_pool_kernel / bwd_pool_kernel) ---------------
+def conv50_pool_supported(x, w, bias, stride, padding, dilation, groups):
+    "``conv50_supported`` + a float32 bias (or none) for the fused conv -> + bias -> ReLU -> MaxPool2d(2)"
+    return (CONV_POOL and conv50_supported(x, w, None, stride, padding, dilation, groups)
+            and (bias is None or (bias.dtype == torch.float32 and tuple(bias.shape) == (50,) and bias.is_cuda)))
+
+
+class _Conv50Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _note_use(w) if bias is None else _note_use(w, bias)
+        x, w = x.contiguous(), w.contiguous()
+        n = x.shape[0]
+        pooled = torch.empty((n, 50, 7, 7), dtype=torch.float32, device=x.device)
+        code = torch.empty((n, 50, 7, 7), dtype=torch.uint8, device=x.device)
+        # the forward launch also leaves the weights as the data gradient reads them (transposed, taps flipped)
+        wT = torch.empty_like(w) if any(ctx.needs_input_grad) else None
+        err = _hip.lib().sgmcmc_conv50_pool_fwd(x.data_ptr(), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                pooled.data_ptr(), code.data_ptr(), 0 if wT is None else wT.data_ptr(),
+                                                n, _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv50_pool_fwd")
+        ctx.save_for_backward(x, w, bias, code)
+        ctx.wT = wT
+        return pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dpooled):
+        lib = _hip.lib()
+        x, w, bias, code = ctx.saved_tensors
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        dpooled = dpooled.contiguous()
+        n = x.shape[0]
+        scratch = torch.empty(lib.sgmcmc_conv50_pool_scratch_floats(n), dtype=torch.float32, device=x.device)
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty_like(bias) if want_b else None
+        want_w = ctx.needs_input_grad[1]
+        defer = want_w and _may_defer(w) and (not want_b or _may_defer(bias))
+        slabs = ctypes.c_int(0)
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        err = lib.sgmcmc_conv50_pool_bwd(x.data_ptr(), ctx.wT.data_ptr(), dpooled.data_ptr(), code.data_ptr(),
+                                         dx.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(),
+                                         scratch.data_ptr(), n, int(want_b), ctypes.byref(slabs) if defer else None,
+                                         _stream())
+        if err:
+            _hip.check(err, "sgmcmc_conv50_pool_bwd")
+        dx = dx if ctx.needs_input_grad[0] else None
+        if not want_w:
+            return dx, None, db
+        if defer:
+            P = slabs.value
+            _pending.append((scratch[:P * 22500], dw, P, 9))
+            if want_b:
+                _pending.append((scratch[P * 22500:], db, P, 1))
+            return dx, dw.view(dw.shape), None if db is None else db.view(db.shape)
+        return dx, dw, db
+
+
+def conv50_pool(x, w, bias=None):
+    "max_pool2d(relu(conv2d(x, w, bias, padding=1)), 2) for x [N, 50, 14, 14], w [50, 50, 3, 3]"
+    return _Conv50Pool.apply(x, w, bias)

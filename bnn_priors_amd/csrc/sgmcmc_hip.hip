@@ -237,14 +237,16 @@ struct ChunkCtx {
   int32_t seg, n_valid;
   int64_t seg_off, arena_off;
 };
-__device__ __forceinline__ ChunkCtx chunk_ctx(const sgmcmc_layout& L, int64_t chunk) {
-  const sgmcmc_chunk ce = L.chunks[chunk];
+__device__ __forceinline__ ChunkCtx chunk_ctx(const sgmcmc_layout& L, int64_t chunk, const sgmcmc_chunk ce) {
   ChunkCtx c;
   c.seg = ce.seg;
   c.n_valid = ce.n_valid;
   c.seg_off = (chunk - L.segs[ce.seg].first_chunk) * L.chunk_elems;
   c.arena_off = chunk * L.chunk_elems;
   return c;
+}
+__device__ __forceinline__ ChunkCtx chunk_ctx(const sgmcmc_layout& L, int64_t chunk) {
+  return chunk_ctx(L, chunk, L.chunks[chunk]);
 }
 
 // ------------------------------------------------------------------ step kernel
@@ -436,12 +438,45 @@ __device__ __forceinline__ void publish_batch_stats(const sgmcmc_layout& L, cons
 
 // PRIOR (without PARTS): g is autograd's gradient of the likelihood term; the closed-form prior gradient is added in
 // flight (SGMCMC_INLINE_PRIOR) instead of by a prior_kernel launch before this one -- as PARTS has always done.
-template <typename T, int KIND, bool VEC, int ITEMS, bool PARTS, bool STREAM = false, bool PRIOR = false>
+// What a graph-replay kernel has in flight BEFORE it knows its scalars (step_early): the chunk's table entries and,
+// on the vector path, its items of m and v -- their addresses follow from the workgroup index alone (the arenas are
+// padded to whole chunks, so the loads are in bounds for a ragged chunk too; its values are then not used).
+template <typename T, int ITEMS>
+struct Early {
+  int64_t chunk;
+  sgmcmc_chunk ce;
+  Item<T> m[ITEMS], v[ITEMS];
+};
+// "All of these are needed HERE": the compiler otherwise sinks each scalar load of a table entry to its first use and
+// waits for them one group at a time -- five dependent round trips to a cold L2 in a kernel whose arithmetic takes
+// a microsecond.  An empty asm that names the values makes them one batch of loads and one wait.
+__device__ __forceinline__ void needed_here(const sgmcmc_step_args& A) {
+  asm volatile("" ::"s"(A.kind), "s"(A.flags), "s"(A.seg_begin), "s"(A.seg_end), "s"(A.chunk_begin), "s"(A.chunk_end),
+               "s"(A.num_data), "s"(A.b2h2), "s"(A.bh), "s"(A.bhn), "s"(A.mom_decay), "s"(A.grad_v), "s"(A.noise_std),
+               "s"(A.rmsprop_alpha), "s"(A.grad_clamp), "s"(A.seed), "s"(A.draw), "s"(A.stream));
+}
+__device__ __forceinline__ void needed_here(const sgmcmc_segment& S) {
+  asm volatile("" ::"s"(S.theta), "s"(S.g), "s"(S.M), "s"(S.numel), "s"(S.first_chunk), "s"(S.noise_base),
+               "s"(S.prior_kind), "s"(S.scale_link), "s"(S.prior_loc), "s"(S.prior_scale), "s"(S.prior_df));
+}
+
+template <typename T, int KIND, bool VEC, int ITEMS, bool PARTS, bool STREAM = false, bool PRIOR = false,
+          bool EARLY = false>
 __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_step_args& A,
-                                          const GradParts& G) {
-  const int64_t chunk = A.chunk_begin + blockIdx.x;
-  const ChunkCtx cx = chunk_ctx(L, chunk);
-  const sgmcmc_segment* __restrict__ sp = &L.segs[cx.seg];
+                                          const GradParts& G, const Early<T, ITEMS>* E = nullptr) {
+  const int64_t chunk = EARLY ? E->chunk : A.chunk_begin + blockIdx.x;
+  const sgmcmc_chunk ce = EARLY ? E->ce : L.chunks[chunk];
+  sgmcmc_segment S;
+  if (EARLY) {
+    S = L.segs[ce.seg];
+    needed_here(S);
+  }
+  const sgmcmc_segment* sp = EARLY ? &S : &L.segs[ce.seg];
+  ChunkCtx cx;
+  cx.seg = ce.seg;
+  cx.n_valid = ce.n_valid;
+  cx.seg_off = (chunk - sp->first_chunk) * L.chunk_elems;
+  cx.arena_off = chunk * L.chunk_elems;
   const double M = sp->M;
   if (!PARTS && sp->g == nullptr) {
     // raise_on_no_grad=False: a tensor without gradient is left untouched -- parameter, momentum,
@@ -495,6 +530,11 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
       if (PARTS) g[it] = sum_parts<T>(pp + j, G.n_slices, G.stride, 4);
       else g[it] = STREAM ? load_item_nt<T>(gp + j) : load_item<T>(gp + j);
       th[it] = STREAM ? load_item_nt<T>(thp + j) : load_item<T>(thp + j);
+      if (EARLY) {
+        m[it] = C.no_mom ? Item<T>{{T(0), T(0), T(0), T(0)}} : E->m[it];
+        v[it] = C.is_final ? Item<T>{{T(0), T(0), T(0), T(0)}} : E->v[it];
+        continue;
+      }
       if (!C.no_mom) m[it] = STREAM ? load_item_nt<T>(mp + j) : load_item<T>(mp + j);
       else m[it] = Item<T>{{T(0), T(0), T(0), T(0)}};
       if (!C.is_final) v[it] = STREAM ? load_item_nt<T>(vp + j) : load_item<T>(vp + j);
@@ -569,10 +609,36 @@ __device__ __forceinline__ void step_body(const sgmcmc_layout& L, const sgmcmc_s
   }
 }
 
+// At BASELINE sizes (314 chunks of 1024 elements) the kernel is a chain of dependent round trips to memory that the
+// kernel boundary has just made cold -- scalars -> chunk table -> segment table -> operands -- not a bandwidth problem.
+// Everything whose address follows from the workgroup index alone is therefore requested up front, next to the scalars
+// (which a graph-replay kernel reads from memory; `chunk_begin` is the host copy's, fixed when the graph is captured):
+// the chunk's table entry and its items of m and v.  The segment's entry is then ONE batch of loads (needed_here);
+// theta and g follow it.  Measured in the googleresnet step: 8.7 -> 7.4-7.9 us.  (A per-chunk pointer
+// table, which lets theta and g leave one trip earlier still, measured no further gain and was not kept.)
+template <typename T, bool VEC, int ITEMS>
+__device__ __forceinline__ Early<T, ITEMS> step_early(const sgmcmc_layout& L, int64_t chunk_begin) {
+  const int64_t chunk = chunk_begin + blockIdx.x;
+  Early<T, ITEMS> E;
+  E.chunk = chunk;
+  if (VEC) {
+    const T* __restrict__ mp = (const T*)L.m + chunk * L.chunk_elems;
+    const T* __restrict__ vp = (const T*)L.v + chunk * L.chunk_elems;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = (it * kThreads + threadIdx.x) * 4;
+      E.m[it] = load_item<T>(mp + j);
+      E.v[it] = load_item<T>(vp + j);
+    }
+  }
+  E.ce = L.chunks[chunk];
+  return E;
+}
 template <typename T, int KIND, bool VEC, int ITEMS>
 __global__ __launch_bounds__(kThreads) void step_kernel(sgmcmc_layout L, sgmcmc_step_args A) {
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
-  step_body<T, KIND, VEC, ITEMS, false>(L, A, none);
+  const Early<T, ITEMS> E = step_early<T, VEC, ITEMS>(L, A.chunk_begin);
+  step_body<T, KIND, VEC, ITEMS, false, false, false, VEC>(L, A, none, &E);
 }
 // arenas beyond the 256 MiB Infinity Cache: every byte is touched once per launch, so the loads
 // and stores are non-temporal (+10 % measured at 2^26..2^28 elements; -9 % if it would have fit)
@@ -583,32 +649,39 @@ __global__ __launch_bounds__(kThreads) void step_kernel_stream(sgmcmc_layout L, 
 }
 // scalars fetched from device memory at run time (graph replay)
 template <typename T, int KIND, bool VEC, int ITEMS>
-__global__ __launch_bounds__(kThreads) void step_kernel_indirect(sgmcmc_layout L,
-                                                                 const sgmcmc_step_args* Ap) {
+__global__ __launch_bounds__(kThreads) void step_kernel_indirect(sgmcmc_layout L, const sgmcmc_step_args* Ap,
+                                                                 int64_t chunk_begin) {
+  const Early<T, ITEMS> E = step_early<T, VEC, ITEMS>(L, chunk_begin);
   const sgmcmc_step_args A = *Ap;
+  needed_here(A);
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
-  step_body<T, KIND, VEC, ITEMS, false>(L, A, none);
+  step_body<T, KIND, VEC, ITEMS, false, false, false, VEC>(L, A, none, &E);
 }
 // ... with the closed-form prior gradient added in flight (SGMCMC_INLINE_PRIOR; float, lean priors)
 template <int KIND, bool VEC, int ITEMS>
-__global__ __launch_bounds__(kThreads) void step_kernel_indirect_prior(sgmcmc_layout L,
-                                                                       const sgmcmc_step_args* Ap) {
+__global__ __launch_bounds__(kThreads) void step_kernel_indirect_prior(sgmcmc_layout L, const sgmcmc_step_args* Ap,
+                                                                       int64_t chunk_begin) {
+  const Early<float, ITEMS> E = step_early<float, VEC, ITEMS>(L, chunk_begin);
   const sgmcmc_step_args A = *Ap;
+  needed_here(A);
   const GradParts none = {nullptr, 0, 0, nullptr, nullptr, 1, 1.0};
-  step_body<float, KIND, VEC, ITEMS, false, false, true>(L, A, none);
+  step_body<float, KIND, VEC, ITEMS, false, false, true, VEC>(L, A, none, &E);
 }
 // ... and the gradient assembled in flight from per-slice partials + closed-form prior
 template <typename T, int KIND, bool VEC, int ITEMS>
-__global__ __launch_bounds__(kThreads) void step_kernel_parts(sgmcmc_layout L,
-                                                              const sgmcmc_step_args* Ap, GradParts G) {
+__global__ __launch_bounds__(kThreads) void step_kernel_parts(sgmcmc_layout L, const sgmcmc_step_args* Ap,
+                                                              GradParts G, int64_t chunk_begin) {
+  const Early<T, ITEMS> E = step_early<T, VEC, ITEMS>(L, chunk_begin);
   const sgmcmc_step_args A = *Ap;
-  step_body<T, KIND, VEC, ITEMS, true>(L, A, G);
+  needed_here(A);
+  step_body<T, KIND, VEC, ITEMS, true, false, false, VEC>(L, A, G, &E);
 }
 
 template <typename T, int KIND, bool VEC, int ITEMS>
 __global__ __launch_bounds__(kThreads) void step_kernel_parts_val(sgmcmc_layout L, sgmcmc_step_args A,
                                                                   GradParts G) {
-  step_body<T, KIND, VEC, ITEMS, true>(L, A, G);
+  const Early<T, ITEMS> E = step_early<T, VEC, ITEMS>(L, A.chunk_begin);
+  step_body<T, KIND, VEC, ITEMS, true, false, false, VEC>(L, A, G, &E);
 }
 
 // ------------------------------------------------------------------ per-segment finalize
@@ -1073,10 +1146,10 @@ template <typename T, int KIND, bool VEC, int ITEMS>
 void launch_step_mode(const sgmcmc_layout& L, const sgmcmc_step_args& A, const sgmcmc_step_args* Ad,
                       const GradParts* G, hipStream_t s) {
   const dim3 grid((unsigned)(A.chunk_end - A.chunk_begin)), block(kThreads);
-  if (G && Ad) SGMCMC_LAUNCH((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G);
+  if (G && Ad) SGMCMC_LAUNCH((step_kernel_parts<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, *G, A.chunk_begin);
   else if (G) SGMCMC_LAUNCH((step_kernel_parts_val<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, A, *G);
-  else if (Ad && (A.flags & SGMCMC_INLINE_PRIOR)) SGMCMC_LAUNCH((step_kernel_indirect_prior<KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
-  else if (Ad) SGMCMC_LAUNCH((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad);
+  else if (Ad && (A.flags & SGMCMC_INLINE_PRIOR)) SGMCMC_LAUNCH((step_kernel_indirect_prior<KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, A.chunk_begin);
+  else if (Ad) SGMCMC_LAUNCH((step_kernel_indirect<T, KIND, VEC, ITEMS>), grid, block, 0, s, L, Ad, A.chunk_begin);
   else if (VEC && ITEMS == 4 &&
            (double)L.n_chunks * (double)L.chunk_elems * sizeof(T) * 7.0 > 224.0 * 1024 * 1024)
     SGMCMC_LAUNCH((step_kernel_stream<T, KIND>), grid, block, 0, s, L, A);

@@ -171,6 +171,12 @@ class _ConvPoolTrunk(nn.Sequential):
             if (isinstance(m, Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                     and _is_pool2(mods[i + 2]) and m.conv_args[3] == 1):
                 w = m.weight                                                    # bias joins the fused tail
+                if _conv.first_pool_supported(x, w, m.bias, *m.conv_args):         # ... or the whole triple is one
+                    x, i = _conv.conv_first_pool(x, w, m.bias), i + 3
+                    continue
+                if _conv.conv50_pool_supported(x, w, m.bias, *m.conv_args):
+                    x, i = _conv.conv50_pool(x, w, m.bias), i + 3
+                    continue
                 if _conv.first_supported(x, w, None, *m.conv_args):
                     y = _conv.conv_first(x, w)
                 elif _conv.conv50_supported(x, w, None, *m.conv_args):

@@ -501,6 +501,18 @@ int sgmcmc_conv_first_fwd(const float* x, const float* w, float* y, int n_img, v
 int64_t sgmcmc_conv_first_scratch_floats(int n_img);
 int sgmcmc_conv_first_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                           int* deferred_slabs, void* stream);
+/* ... and the layer WITH its tail, Conv2d(1, 50, 3, padding=1) -> + bias -> ReLU -> MaxPool2d(2)
+ * (models/conv_nets.py:46-57), one launch each way; the 50 x 28 x 28 map is never written.
+ *   fwd: pooled [n][50][14][14] and code [n][50][14][14] bytes -- bits 0-1 the window position of the first maximum
+ *        in scan order (NaNs win, as ATen's max_pool2d), bit 2 set when max + bias > 0.
+ *   bwd: from the gradient w.r.t. pooled and code: weight-gradient slabs [P][450] at scratch and, with want_bias,
+ *        bias-gradient slabs [P][50] behind them (P = 7 n_img bands); reduced into dw / dbias here, or --
+ *        deferred_slabs != NULL -- *deferred_slabs = P and the caller runs sgmcmc_wrw_reduce_many over both. */
+int sgmcmc_conv_first_pool_fwd(const float* x, const float* w, const float* bias, float* pooled, uint8_t* code,
+                               int n_img, void* stream);
+int64_t sgmcmc_conv_first_pool_scratch_floats(int n_img);
+int sgmcmc_conv_first_pool_bwd(const float* x, const float* dpooled, const uint8_t* code, float* dw, float* dbias,
+                               float* scratch, int n_img, int want_bias, int* deferred_slabs, void* stream);
 
 /* The convolutional classifier's SECOND convolution (models/conv_nets.py:46-70): 50 -> 50 channels, 3x3 / stride 1 /
  * pad 1 on 14x14 maps, without its bias (see sgmcmc_bias_relu_pool_*), on the fp32 matrix pipe (csrc/conv50_hip.inc).
@@ -518,6 +530,19 @@ int sgmcmc_conv50_bwd(const float* x, const float* w, const float* dy, float* dx
 int sgmcmc_conv50_fwd(const float* x, const float* w, float* y, float* wT, int n_img, void* stream);
 int sgmcmc_conv50_bwd_t(const float* x, const float* wT, const float* dy, float* dx, float* dw, float* scratch,
                         int n_img, int* deferred_slabs, void* stream);
+/* ... and the layer WITH its tail, Conv2d(50, 50, 3, padding=1) -> + bias -> ReLU -> MaxPool2d(2)
+ * (models/conv_nets.py:58-66), one launch each way; the 50 x 14 x 14 map and its gradient exist in LDS only.
+ *   fwd: pooled [n][50][7][7], code [n][50][7][7] bytes (encoding of sgmcmc_conv_first_pool_fwd), wT as
+ *        sgmcmc_conv50_fwd (may be NULL).
+ *   bwd: from the gradient w.r.t. pooled and code: dx [n][50][14][14] (required), weight-gradient slabs [P][22500]
+ *        (tap-major) at scratch and, with want_bias, bias-gradient slabs [P][50] behind them (P = ceil(n_img / 2));
+ *        reduced into dw / dbias here, or -- deferred_slabs != NULL -- left to sgmcmc_wrw_reduce_many. */
+int sgmcmc_conv50_pool_fwd(const float* x, const float* w, const float* bias, float* pooled, uint8_t* code, float* wT,
+                           int n_img, void* stream);
+int64_t sgmcmc_conv50_pool_scratch_floats(int n_img);
+int sgmcmc_conv50_pool_bwd(const float* x, const float* wT, const float* dpooled, const uint8_t* code, float* dx,
+                           float* dw, float* dbias, float* scratch, int n_img, int want_bias, int* deferred_slabs,
+                           void* stream);
 
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,

@@ -322,6 +322,132 @@ def test_first_layer_convolution_matches_float64_reference(n):
     assert torch.equal(w2.grad, wg.grad + wg.grad) and not conv._pending
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 5, 1])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_first_layer_with_its_tail_equals_the_two_operators(n, with_bias):
+    """conv -> + bias -> ReLU -> MaxPool2d(2) in one launch each way (convfirst::fwd_pool_kernel / wrw_pool_kernel):
+    the pooled map and the weight gradient carry the bits of conv_first -> bias_relu_pool (same contraction, same
+    order), the bias gradient agrees to rounding (its partial sums are per band instead of per image slice); ties and
+    exact zeros in the window go to the first position in scan order / do not pass the ReLU, as in ATen."""
+    from bnn_priors_amd import conv, pool
+    g = torch.Generator().manual_seed(11 + n)
+    x = torch.randn(n, 1, 28, 28, generator=g)
+    x[:, :, 4:8, 4:12] = 0.0                         # flat patches: tied windows
+    x = x.cuda()
+    w = (torch.randn(50, 1, 3, 3, generator=g) / 3).cuda()
+    b = (torch.randn(50, generator=g) / 4).cuda() if with_bias else None
+    if with_bias:
+        b[:5] = 0.0                                  # max + bias == 0 on the flat patches: the ReLU's edge
+    dy = torch.randn(n, 50, 14, 14, generator=g).cuda()
+    w0 = w.clone().requires_grad_()
+    b0 = b.clone().requires_grad_() if with_bias else None
+    ref = pool.bias_relu_pool(conv.conv_first(x, w0), b0)
+    ref.backward(dy)
+    w1 = w.clone().requires_grad_()
+    b1 = b.clone().requires_grad_() if with_bias else None
+    assert conv.first_pool_supported(x, w1, b1, 1, 1, 1, 1)
+    out = conv.conv_first_pool(x, w1, b1)
+    out.backward(dy)
+    assert torch.equal(out, ref)
+    assert torch.equal(w1.grad, w0.grad) and not conv._pending
+    if with_bias:
+        torch.testing.assert_close(b1.grad, b0.grad, rtol=1e-5, atol=1e-4 * max(1.0, n ** .5))
+    # ... and against ATen in float64
+    wd = w.double().requires_grad_()
+    bd = b.double().requires_grad_() if with_bias else None
+    refd = F.max_pool2d(F.relu(F.conv2d(x.double(), wd, bd, padding=1)), 2)
+    refd.backward(dy.double())
+    eps = torch.finfo(torch.float32).eps
+    assert (out.double() - refd.detach()).abs().max() <= 64 * eps * max(1.0, refd.abs().max().item())
+    # (a window whose two largest entries differ by less than fp32 rounding may route its gradient elsewhere)
+    close = (w1.grad.double() - wd.grad).abs().max() / max(1.0, wd.grad.abs().max().item())
+    assert close <= 1e-3, close
+    with torch.no_grad():                            # evaluation: forward alone
+        assert torch.equal(conv.conv_first_pool(x, w, b), ref)
+
+
+@pytest.mark.gpu
+def test_first_layer_with_its_tail_defers_both_gradients_inside_the_samplers_pass():
+    from bnn_priors_amd import conv
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 1, 28, 28, generator=g).cuda()
+    w = (torch.randn(50, 1, 3, 3, generator=g) / 3).cuda().requires_grad_()
+    b = (torch.randn(50, generator=g) / 4).cuda().requires_grad_()
+    dy = torch.randn(16, 50, 14, 14, generator=g).cuda()
+    conv.conv_first_pool(x, w, b).backward(dy)
+    gw, gb = w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    with conv.deferring():
+        conv.conv_first_pool(x, w, b).backward(dy)
+    assert not conv._pending
+    assert torch.equal(w.grad, gw) and torch.equal(b.grad, gb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 5, 1])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_second_layer_with_its_tail_equals_the_two_operators(n, with_bias):
+    """conv50 -> + bias -> ReLU -> MaxPool2d(2) in one launch each way (conv50::conv_pool_kernel / bwd_pool_kernel):
+    pooled map, data gradient and weight gradient carry the bits of conv50 -> bias_relu_pool (the 14 x 14 map and its
+    gradient are rebuilt in LDS with the same values), the bias gradient agrees to rounding."""
+    from bnn_priors_amd import conv, pool
+    g = torch.Generator().manual_seed(50 + n)
+    x = torch.randn(n, 50, 14, 14, generator=g)
+    x[:, :, 2:6, 2:8] = 0.0                          # flat patches: tied windows, max + bias == 0 where bias is 0
+    x = x.cuda()
+    w = (torch.randn(50, 50, 3, 3, generator=g) / 21).cuda()
+    b = (torch.randn(50, generator=g) / 4).cuda() if with_bias else None
+    if with_bias:
+        b[:5] = 0.0
+    dy = torch.randn(n, 50, 7, 7, generator=g).cuda()
+    x0, w0 = x.clone().requires_grad_(), w.clone().requires_grad_()
+    b0 = b.clone().requires_grad_() if with_bias else None
+    ref = pool.bias_relu_pool(conv.conv50(x0, w0), b0)
+    ref.backward(dy)
+    x1, w1 = x.clone().requires_grad_(), w.clone().requires_grad_()
+    b1 = b.clone().requires_grad_() if with_bias else None
+    assert conv.conv50_pool_supported(x1, w1, b1, 1, 1, 1, 1)
+    out = conv.conv50_pool(x1, w1, b1)
+    out.backward(dy)
+    assert torch.equal(out, ref)
+    assert torch.equal(x1.grad, x0.grad)
+    assert torch.equal(w1.grad, w0.grad) and not conv._pending
+    if with_bias:
+        torch.testing.assert_close(b1.grad, b0.grad, rtol=1e-5, atol=1e-4 * max(1.0, n ** .5))
+    wd, xd = w.double().requires_grad_(), x.double().requires_grad_()
+    bd = b.double().requires_grad_() if with_bias else None
+    refd = F.max_pool2d(F.relu(F.conv2d(xd, wd, bd, padding=1)), 2)
+    eps = torch.finfo(torch.float32).eps
+    assert (out.double() - refd.detach()).abs().max() <= 256 * eps * max(1.0, refd.abs().max().item())
+    with torch.no_grad():
+        assert torch.equal(conv.conv50_pool(x, w, b), ref)
+    # only the input takes a gradient / only the parameters do
+    x2 = x.clone().requires_grad_()
+    conv.conv50_pool(x2, w, b).backward(dy)
+    assert torch.equal(x2.grad, x0.grad)
+    w3 = w.clone().requires_grad_()
+    conv.conv50_pool(x, w3, b).backward(dy)
+    assert torch.equal(w3.grad, w0.grad)
+
+
+@pytest.mark.gpu
+def test_second_layer_with_its_tail_defers_both_gradients_inside_the_samplers_pass():
+    from bnn_priors_amd import conv
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(9, 50, 14, 14, generator=g).cuda().requires_grad_()
+    w = (torch.randn(50, 50, 3, 3, generator=g) / 21).cuda().requires_grad_()
+    b = (torch.randn(50, generator=g) / 4).cuda().requires_grad_()
+    dy = torch.randn(9, 50, 7, 7, generator=g).cuda()
+    conv.conv50_pool(x, w, b).backward(dy)
+    gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+    x.grad = w.grad = b.grad = None
+    with conv.deferring():
+        conv.conv50_pool(x, w, b).backward(dy)
+    assert not conv._pending
+    assert torch.equal(x.grad, gx) and torch.equal(w.grad, gw) and torch.equal(b.grad, gb)
+
+
 # ------------------------------------------------------------------ deferred weight-gradient reduction
 def _conv_mod():
     from bnn_priors_amd import conv

@@ -64,8 +64,18 @@ def test_convnet_takes_the_fused_tail(monkeypatch):
     kw = dict(width=50, depth=3, weight_prior="laplace", weight_loc=0., weight_scale=2 ** .5, bias_prior="gaussian",
               bias_loc=0., bias_scale=1., batchnorm=True, weight_prior_params={}, bias_prior_params={})
     net = models.get_model(x, y, "classificationconvnet", **kw).cuda()
+    from bnn_priors_amd import conv
+    fused = net.net(x.cuda())
+    assert calls == []                  # round 3: each conv -> + bias -> ReLU -> pool triple is ONE operator ...
+    monkeypatch.setattr(conv, "CONV_POOL", False)
     out = net.net(x.cuda())
-    assert calls == [(50, 28, 28), (50, 14, 14)]
+    assert calls == [(50, 28, 28), (50, 14, 14)]       # ... and without it, convolution + fused tail
+    assert torch.equal(fused, out)
+    net.zero_grad()
+    monkeypatch.setattr(conv, "CONV_POOL", True)
+    F.cross_entropy(net.net(x.cuda()), y.cuda()).backward()
+    fused_grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    monkeypatch.setattr(conv, "CONV_POOL", False)
     monkeypatch.setattr(pool, "ENABLED", False)
     calls.clear()
     ref = net.net(x.cuda())
@@ -80,6 +90,7 @@ def test_convnet_takes_the_fused_tail(monkeypatch):
         grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
     for k in grads[0]:
         torch.testing.assert_close(grads[0][k], grads[1][k], rtol=1e-4, atol=1e-5 * max(1.0, grads[1][k].abs().max().item()), msg=k)
+        torch.testing.assert_close(fused_grads[k], grads[1][k], rtol=1e-4, atol=1e-5 * max(1.0, grads[1][k].abs().max().item()), msg=k)
 
 
 @pytest.mark.gpu
