@@ -274,6 +274,29 @@ def conv_rooflines(device, n_img=128, iters=60):
     return rows
 
 
+def attach_pmc_traffic(rows):
+    """`traffic` of the rows that profiles/pmc_traffic.json covers: HBM bytes per launch from a rocprofv3 --pmc pass
+    (FETCH_SIZE doubled as the guide prescribes for gfx950, + WRITE_SIZE) over the same kernels at the same shapes.
+    Counters cannot be collected from inside this process; the file is a committed measurement (tools/pmc_to_json.py
+    names the pass) and `traffic_source` says so.  Rows it does not cover keep traffic = null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return rows
+    for r in rows:
+        k = pmc.get("kernels", {}).get(r.get("kernel"))
+        if k and r.get("shape", {}).get("n") == 128:
+            r["traffic"] = k["read_bytes"] + k["write_bytes"]
+            r["traffic_unit"] = "bytes per launch (HBM read + write)"
+            if "traffic_over_algorithmic" in k:
+                r["algorithmic_bytes_per_launch"] = k["algorithmic_bytes"]
+                r["traffic_over_algorithmic"] = k["traffic_over_algorithmic"]
+            r["traffic_source"] = "profiles/pmc_traffic.json <- " + pmc.get("source", "?")
+    return rows
+
+
 def bn_rooflines(device, n_img=128, iters=60):
     """The trunk's BatchNorm kernels against HBM: ``bn::apply_kernel`` (normalise + [residual] + ReLU from the
     producing convolution's statistics partials) and ``bn::bwd_dx_kernel`` (the whole BatchNorm backward given the
@@ -837,7 +860,7 @@ def main():
         if args.workload == "googleresnet" and not args.no_kernel_timing:
             # the step is dominated by the trunk's convolution gradients (profiles/): the headline roofline is
             # the kernel with the largest share of the step, the sampler's HBM line is reported beside it
-            convs = conv_rooflines(device)
+            convs = attach_pmc_traffic(conv_rooflines(device))
             try:
                 bns = bn_rooflines(device)
             except Exception as exc:       # (an extra table: never takes the bench line down)
