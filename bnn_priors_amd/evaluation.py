@@ -121,6 +121,27 @@ def _predictive_tables_batched(model, dataloader_test, samples, labels, E, C):
 EVAL_GRAPH = os.environ.get("SGMCMC_EVAL_GRAPH", "1") != "0"
 
 
+# rows per evaluation forward (0: the loader's own batches)
+EVAL_ROWS = int(os.environ.get("SGMCMC_EVAL_ROWS", "1024"))
+
+
+def _row_groups(dataloader, device, rows):
+    "the loader's batches, consecutive ones concatenated up to ``rows`` rows (order kept; the last group is what is left)"
+    if rows <= 0:
+        yield from dataloader
+        return
+    xs, ys, have = [], [], 0
+    for bx, by in dataloader:
+        if xs and have + len(bx) > rows:
+            yield (torch.cat(xs), torch.cat(ys)) if len(xs) > 1 else (xs[0], ys[0])
+            xs, ys, have = [], [], 0
+        xs.append(bx.to(device))
+        ys.append(by.to(device))
+        have += len(bx)
+    if xs:
+        yield (torch.cat(xs), torch.cat(ys)) if len(xs) > 1 else (xs[0], ys[0])
+
+
 class _GraphedLogits:
     def __init__(self, model, x):
         self.shape, self.dtype = tuple(x.shape), x.dtype
@@ -191,7 +212,10 @@ def predictive_tables(model, dataloader_test, samples):
     for e in range(E):
         model.load_state_dict({k: v[e] for k, v in samples.items()})
         i = 0
-        for bx, by in dataloader_test:
+        # evaluation mode makes every row's prediction a function of that row alone, so the loader's batches are
+        # evaluated several at a time (EVAL_ROWS rows per forward): 10 launch-bound forwards of 1,024 rows instead of
+        # 79 of 128 for a CIFAR-10 test set -- same numbers row by row (the kernels' arithmetic is per image)
+        for bx, by in (_row_groups(dataloader_test, device, EVAL_ROWS) if graphed and plain_temp else dataloader_test):
             bx, by = bx.to(device), by.to(device)
             if graphed and plain_temp:
                 # the numbers ``model(bx)`` = Categorical(logits=net(x) / T) would hold -- normalised logits and

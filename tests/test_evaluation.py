@@ -62,3 +62,29 @@ def test_grouped_evaluation_on_gpu_matches_the_loop_and_is_taken(name, monkeypat
         assert got[k] == pytest.approx(want[k], rel=2e-4, abs=2e-4), k
     from bnn_priors_amd import conv
     assert conv.ENABLED                                     # the layer switches are restored
+
+
+def test_row_groups_concatenate_consecutive_batches_in_order():
+    x = torch.arange(100, dtype=torch.float32).view(100, 1)
+    y = torch.arange(100)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=16)
+    groups = list(ev._row_groups(loader, "cpu", 40))                  # 16 + 16 | 16 + 16 | 16 + 16 + 4
+    assert [len(gx) for gx, _ in groups] == [32, 32, 36]
+    assert torch.equal(torch.cat([gx for gx, _ in groups]), x) and torch.equal(torch.cat([gy for _, gy in groups]), y)
+    assert [len(gx) for gx, _ in ev._row_groups(loader, "cpu", 0)] == [16] * 6 + [4]      # 0: the loader's own batches
+    assert [len(gx) for gx, _ in ev._row_groups(loader, "cpu", 8)] == [16] * 6 + [4]      # never splits a batch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["classificationconvnet", "googleresnet"])
+def test_evaluating_several_batches_per_forward_gives_the_same_rows(name, monkeypatch):
+    """E = 1 (the per-epoch evaluation): the loader's batches concatenated up to EVAL_ROWS rows per forward -- the
+    per-image kernels give every row the same bits as batch-by-batch evaluation"""
+    net, loader, samples, y = _setup(name, n=200, E=1, device="cuda:0")
+    tables = {}
+    for rows in (0, 96, 1024):
+        monkeypatch.setattr(ev, "EVAL_ROWS", rows)
+        lps, acc, labels, kind = ev.predictive_tables(net, loader, samples)
+        tables[rows] = (lps.clone(), acc.clone())
+    for rows in (96, 1024):
+        assert torch.equal(tables[rows][0], tables[0][0]) and torch.equal(tables[rows][1], tables[0][1]), rows

@@ -22,7 +22,7 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     w = torch.randn((c, c, 3, 3), generator=g, device=dev) * (2.0 / (9 * c)) ** .5
     res = torch.randn((n, c, hw, hw), generator=g, device=dev)
     dout = torch.randn((n, c, hw, hw), generator=g, device=dev)
-    y, out, dx, dres = (torch.empty_like(x) for _ in range(4))
+    y, out, dx_, dres = (torch.empty_like(x) for _ in range(4))
     slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
     stats = torch.empty((c, slices, 2), dtype=torch.float64, device=dev)
     _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s), "conv")
@@ -36,12 +36,28 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
         return lib.sgmcmc_bn_train_fwd(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
                                        1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 0,
                                        stats.data_ptr(), slices, s)
+    stats8 = stats[:, :8].contiguous()          # (timing only) what a prologue over 8 partial pairs per channel costs
+    part = torch.randn((c, slices, 2), generator=g, device=dev, dtype=torch.float64)
+    part8 = part[:, :8].contiguous()
+
+    def fwd8(r):
+        return lib.sgmcmc_bn_train_fwd(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
+                                       1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 0,
+                                       stats8.data_ptr(), 8, s)
+
+    def dx(pt, k):
+        return lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(),
+                                    saved[1].data_ptr(), 1, n, c, hw * hw, pt.data_ptr(), k, dx_.data_ptr(), 0,
+                                    dgb[0].data_ptr(), dgb[1].data_ptr(), None, s)
     cases = {
+        "apply, 8 partials per channel": lambda: fwd8(0),
+        f"bwd_dx, {slices} partials per channel": lambda: dx(part, slices),
+        "bwd_dx, 8 partials per channel": lambda: dx(part8, 8),
         "apply": lambda: fwd(0),
         "apply+res": lambda: fwd(res.data_ptr()),
         "bwd_sums (first launch of bwd)": lambda: lib.sgmcmc_bn_train_bwd(
             dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 1, n, c,
-            hw * hw, dx.data_ptr(), 0, dgb[0].data_ptr(), dgb[1].data_ptr(), scratch.data_ptr(), s),
+            hw * hw, dx_.data_ptr(), 0, dgb[0].data_ptr(), dgb[1].data_ptr(), scratch.data_ptr(), s),
     }
     for name, fn in cases.items():
         for _ in range(5):

@@ -5,3 +5,4 @@ cd "$(dirname "$0")"
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I ../../include -I ../../bnn_priors_amd/csrc"
 hipcc $F -DNO_STAMPS lab.hip -o lab && hipcc $F lab.hip -o lab_st
 hipcc $F -DNO_STAMPS lab50.hip -o lab50 && hipcc $F lab50.hip -o lab50_st
+hipcc $F atom.hip -o atom
