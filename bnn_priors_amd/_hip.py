@@ -93,6 +93,14 @@ class BnResidualSums(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("y", "mean", "invstd", "partial")]
 
 
+class BnDual(ctypes.Structure):
+    "sgmcmc_bn_dual"
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("r", "gamma", "beta", "partial")]
+                + [("n_partials", ctypes.c_int32), ("reserved", ctypes.c_int32), ("eps", ctypes.c_double),
+                   ("momentum", ctypes.c_double)]
+                + [(n, ctypes.c_void_p) for n in ("save_mean", "save_invstd", "running_mean", "running_var", "stat_log")])
+
+
 class ConvBnBwdArgs(ctypes.Structure):
     "sgmcmc_conv_bn_bwd_args"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("dout", "mask_out", "y", "mean", "invstd", "gamma", "sums")]
@@ -197,6 +205,9 @@ EXPORTS = {
     "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
                             + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_bn_train_fwd_dual": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double, ctypes.c_double]
+                                 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p,
+                                                                                 ctypes.POINTER(BnDual), ctypes.c_void_p]),
     "sgmcmc_bn_train_fwd_log": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double] + [ctypes.c_int] * 4
                                 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_running_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,

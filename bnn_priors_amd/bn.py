@@ -197,6 +197,98 @@ class _BNTrain(torch.autograd.Function):
         return (dx, dwb[0], dwb[1], dres) + (None,) * 8
 
 
+# ---- relu(BN(x) + BN_s(r)): the last BatchNorm of a down-sampling block with the shortcut's BatchNorm applied on the fly
+# (csrc/bn_hip.inc apply_dual_kernel).  SGMCMC_BN_DUAL=0 restores the two operators (A/B runs, the tests' cross-check).
+DUAL = os.environ.get("SGMCMC_BN_DUAL", "1") != "0"
+
+
+def dual_supported(x, stats, r, r_stats, bn, bn_s):
+    "both layers in training mode with running statistics, float32 affine, statistics from their convolutions' epilogues"
+    if not (DUAL and stats is not None and r_stats is not None and r.shape == x.shape and r.dtype == x.dtype):
+        return False
+    for layer in (bn, bn_s):
+        if not (layer.training and layer.track_running_stats and layer.momentum is not None and layer.affine
+                and supported(x, layer.weight, layer.bias, True, layer.momentum)):
+            return False
+    return True
+
+
+class _BNTrainDual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stats_in, r, r_weight, r_bias, r_stats, main, short):
+        "main / short: (running_mean, running_var, momentum, eps) of the two layers"
+        lib = _hip.lib()
+        x, r = x.contiguous(), r.contiguous()
+        n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        y = torch.empty_like(x)
+        saved = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        r_saved = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        slot, r_slot = log_slot(main[0]), log_slot(short[0])
+        R = _hip.BnDual(r=r.data_ptr(), gamma=r_weight.data_ptr(), beta=r_bias.data_ptr(), partial=r_stats.data_ptr(),
+                        n_partials=r_stats.shape[1], reserved=0, eps=float(short[3]), momentum=float(short[2]),
+                        save_mean=r_saved[0].data_ptr(), save_invstd=r_saved[1].data_ptr(),
+                        running_mean=0 if r_slot is not None else short[0].data_ptr(),
+                        running_var=0 if r_slot is not None else short[1].data_ptr(), stat_log=_ptr(r_slot))
+        err = lib.sgmcmc_bn_train_fwd_dual(x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                           0 if slot is not None else main[0].data_ptr(),
+                                           0 if slot is not None else main[1].data_ptr(), float(main[2]), float(main[3]),
+                                           n, c, plane, y.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(),
+                                           stats_in.data_ptr(), stats_in.shape[1], _ptr(slot), ctypes.byref(R),
+                                           torch.cuda.current_stream().cuda_stream)
+        if err:
+            _hip.check(err, "sgmcmc_bn_train_fwd_dual")
+        ctx.save_for_backward(x, weight, y, saved, r, r_weight, r_saved)
+        ctx.mark_non_differentiable(saved)
+        ctx.set_materialize_grads(False)
+        return y, saved
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, *_):
+        "the two layers' backward as _BNTrain runs them: dx with the shortcut's sums riding along, then the shortcut's dx"
+        lib = _hip.lib()
+        x, weight, y, saved, r, r_weight, r_saved = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 10
+        up = _bnlink.sums_of(dy)
+        dy = dy.contiguous()
+        n, c, plane = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        st = torch.cuda.current_stream().cuda_stream
+        if up is None:
+            sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+            n_sums = ctypes.c_int(0)
+            err = lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), y.data_ptr(), x.data_ptr(), saved[0].data_ptr(),
+                                         saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, plane, st)
+            if err:
+                _hip.check(err, "sgmcmc_bn_bwd_sums")
+            up = (sums, n_sums.value)
+        dx, dz, dr = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        dwb = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)
+        r_part = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane), dtype=torch.float64, device=x.device)
+        R = _hip.BnResidualSums(y=r.data_ptr(), mean=r_saved[0].data_ptr(), invstd=r_saved[1].data_ptr(),
+                                partial=r_part.data_ptr())
+        err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), y.data_ptr(), x.data_ptr(), weight.data_ptr(), saved[0].data_ptr(),
+                                   saved[1].data_ptr(), 1, n, c, plane, up[0].data_ptr(), up[1], dx.data_ptr(),
+                                   dz.data_ptr(), dwb[0, 0].data_ptr(), dwb[0, 1].data_ptr(), ctypes.byref(R), st)
+        if err:
+            _hip.check(err, "sgmcmc_bn_bwd_dx")
+        err = lib.sgmcmc_bn_bwd_dx(dz.data_ptr(), 0, r.data_ptr(), r_weight.data_ptr(), r_saved[0].data_ptr(),
+                                   r_saved[1].data_ptr(), 0, n, c, plane, r_part.data_ptr(), r_part.numel() // (2 * c),
+                                   dr.data_ptr(), 0, dwb[1, 0].data_ptr(), dwb[1, 1].data_ptr(), None, st)
+        if err:
+            _hip.check(err, "sgmcmc_bn_bwd_dx(shortcut)")
+        return dx, dwb[0, 0], dwb[0, 1], None, dr, dwb[1, 0], dwb[1, 1], None, None, None
+
+
+def bn_train_dual(x, stats, bn, r, r_stats, bn_s):
+    "relu(bn(x) + bn_s(r)) for two training-mode BatchNorm2d modules that pass ``dual_supported``"
+    out, saved = _BNTrainDual.apply(x, bn.weight, bn.bias, stats, r, bn_s.weight, bn_s.bias, r_stats,
+                                    (bn.running_mean, bn.running_var, bn.momentum, bn.eps),
+                                    (bn_s.running_mean, bn_s.running_var, bn_s.momentum, bn_s.eps))
+    _bnlink.tag_output(out, x, saved)     # a convolution that consumes `out` can produce this BatchNorm's backward sums
+    return out
+
+
 def bn_train(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, stats=None):
     """``stats``: per-slice partial (sum, sum of squared deviations from the slice mean) of x over equal parts of (N, H, W) per channel, float64
     [channels][slices][2], if the producer of x already has them (``conv.conv3x3(..., want_stats=True)``);

@@ -337,6 +337,12 @@ class BasicBlock(nn.Module):
                 want = m[1].training and m[1].track_running_stats and _bn.ENABLED
                 ym, ys, *st = _conv.conv_down(x, m[0].weight, sc[0].weight, want)
                 h = m[1].fused(ym, relu=True, stats=st[0] if want else None)
+                if want and isinstance(m[3], Conv2d) and isinstance(m[4], _BatchNorm2d):
+                    # the shortcut's BatchNorm is applied inside the block's last BatchNorm launch (bn.bn_train_dual)
+                    y2, st2 = m[3](h, want_stats=True)
+                    if _bn.dual_supported(y2, st2, ys, st[1], m[4], sc[1]):
+                        return _bn.bn_train_dual(y2, st2, m[4], ys, st[1], sc[1])
+                    return m[4].fused(y2, sc[1].fused(ys, stats=st[1]), True, st2)
                 skip = sc[1].fused(ys, stats=st[1] if want else None)
             else:
                 h = _conv_bn(m[0], m[1], x, relu=True)

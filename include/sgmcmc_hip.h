@@ -588,6 +588,26 @@ int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const f
  * down-sampling block's shortcut, models/google_resnet.py:77-90) whose incoming gradient is dresidual; the launch
  * also leaves that BatchNorm's backward sums in rs->partial, [channels][sgmcmc_bn_scratch_doubles(...) / (2
  * channels)][2] doubles (the slices of this launch's own geometry). */
+/* out = relu(BN(x) + BN_s(r)): a down-sampling block's last BatchNorm (models/google_resnet.py:77-90) with the 1x1
+ * shortcut's BatchNorm -- no ReLU, this sum its only consumer -- applied on the fly: the shortcut BatchNorm's own
+ * launch and its output tensor disappear; the same bits as sgmcmc_bn_train_fwd twice.  Training mode; both layers'
+ * batch statistics as equal-part partial pairs [channels][slices][2] (a convolution epilogue's); save_* / running_* /
+ * stat_log per layer as for sgmcmc_bn_train_fwd[_log]. */
+typedef struct {
+  const float* r;     /* the shortcut BatchNorm's input */
+  const float* gamma;
+  const float* beta;
+  const double* partial;
+  int n_partials, reserved;
+  double eps, momentum;
+  float *save_mean, *save_invstd, *running_mean, *running_var;
+  double* stat_log;
+} sgmcmc_bn_dual;
+int sgmcmc_bn_train_fwd_dual(const float* x, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, double momentum, double eps, int n, int channels, int plane, float* y,
+                             float* save_mean, float* save_invstd, const double* stats_in, int stats_slices,
+                             double* stat_log, const sgmcmc_bn_dual* rs, void* stream);
+
 typedef struct {
   const float *y, *mean, *invstd; /* the residual BatchNorm's input and saved statistics */
   double* partial;

@@ -184,3 +184,65 @@ def test_eval_mode_forward_of_the_resnet_runs_on_this_packages_kernels():
             for m, v in zip(mods, old):
                 m.ENABLED = v
     torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,hw,n", [(16, 32, 128), (32, 16, 128), (16, 32, 5)])
+def test_down_sampling_block_with_the_shortcut_batchnorm_applied_on_the_fly_has_the_bits_of_two_launches(cin, hw, n, monkeypatch):
+    """relu(BN(conv2(h)) + BN_s(shortcut(x))) in ONE launch (bn.bn_train_dual): output, every gradient, the saved and the
+    running statistics of both layers are bit-identical to the two-operator route; so is the logging mode."""
+    from bnn_priors_amd import bn as bnmod
+    from bnn_priors_amd import conv
+    from bnn_priors_amd.models import nets
+    from bnn_priors_amd import prior
+
+    def make():
+        torch.manual_seed(3)
+        kw = dict(prior_w=prior.Normal, loc_w=0., std_w=2 ** .5, prior_b=None, scaling_fn=None, weight_prior_params={},
+                  bias_prior_params={})
+        blk = nets.BasicBlock(cin, 2 * cin, 2, kw, nets._BatchNorm2d).cuda().train()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, nets._BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.5, 0.5)
+        return blk
+
+    g = torch.Generator().manual_seed(cin + n)
+    x = torch.randn(n, cin, hw, hw, generator=g).cuda()
+    dout = torch.randn(n, 2 * cin, hw // 2, hw // 2, generator=g).cuda()
+    results = []
+    for dual in (True, False):
+        monkeypatch.setattr(bnmod, "DUAL", dual)
+        blk = make()
+        calls = []
+        real = bnmod.bn_train_dual
+        monkeypatch.setattr(bnmod, "bn_train_dual", lambda *a: (calls.append(1), real(*a))[1])
+        xg = x.clone().requires_grad_()
+        out = blk(xg)
+        out.backward(dout)
+        assert bool(calls) == dual
+        monkeypatch.setattr(bnmod, "bn_train_dual", real)
+        results.append((out.detach(), xg.grad, {k: p.grad for k, p in blk.named_parameters()},
+                        {k: v.clone() for k, v in blk.named_buffers()}))
+    (o1, gx1, gp1, b1), (o0, gx0, gp0, b0) = results
+    assert torch.equal(o1, o0) and torch.equal(gx1, gx0)
+    for k in gp0:
+        assert torch.equal(gp1[k], gp0[k]), k
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k
+    # logging mode: the batch statistics go to the slots, the running statistics stay
+    blk = make()
+    bns = [m for m in blk.modules() if isinstance(m, nets._BatchNorm2d)]
+    logs = {}
+    for dual in (True, False):
+        monkeypatch.setattr(bnmod, "DUAL", dual)
+        slots = {id(m.running_mean): torch.zeros((m.num_features, 2), dtype=torch.float64, device="cuda") for m in bns}
+        before = [m.running_mean.clone() for m in bns]
+        with torch.no_grad(), bnmod.logging_running_stats(slots):
+            out = blk(x)
+        assert all(torch.equal(m.running_mean, b) for m, b in zip(bns, before))
+        logs[dual] = (out, [slots[id(m.running_mean)].clone() for m in bns])
+    assert torch.equal(logs[True][0], logs[False][0])
+    for a, b in zip(logs[True][1], logs[False][1]):
+        assert torch.equal(a, b) and a.abs().sum() > 0
