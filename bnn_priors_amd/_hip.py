@@ -101,6 +101,13 @@ class BnDual(ctypes.Structure):
                 + [(n, ctypes.c_void_p) for n in ("save_mean", "save_invstd", "running_mean", "running_var", "stat_log")])
 
 
+class BnIn(ctypes.Structure):
+    "sgmcmc_bn_in"
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("fx", "gamma", "beta", "save_mean", "save_invstd", "running_mean",
+                                                "running_var", "stat_log")]
+                + [("momentum", ctypes.c_double), ("eps", ctypes.c_double), ("h", ctypes.c_void_p)])
+
+
 class ConvBnBwdArgs(ctypes.Structure):
     "sgmcmc_conv_bn_bwd_args"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("dout", "mask_out", "y", "mean", "invstd", "gamma", "sums")]
@@ -205,6 +212,10 @@ EXPORTS = {
     "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
                             + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_fx_slot_int64": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv3x3_fx": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bnin": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
+                            + [ctypes.c_void_p, ctypes.POINTER(BnIn), ctypes.c_void_p]),
     "sgmcmc_bn_train_fwd_dual": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double, ctypes.c_double]
                                  + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p,
                                                                                  ctypes.POINTER(BnDual), ctypes.c_void_p]),

@@ -107,6 +107,45 @@ def frags(w):
 # Everywhere else -- user code calling these operators directly -- the reduction is launched immediately.
 _defer = {"active": False, "uses": {}, "weights": {}}
 
+# ---- zeroed integer slots for grid-wide sums (csrc/conv_hip.inc namespace fx) ---------------------------------------
+# A launch that leaves per-channel sums in fx slots ADDS to them, so they have to be zero beforehand.  Inside a
+# ``deferring`` scope the slots of a pass are slices of ONE arena zeroed by one launch: a fresh arena per captured graph
+# (its memset is a node of that graph; graphs of one model replay concurrently on their own streams), a persistent one
+# per (owner, stream) for eager passes.  Outside a scope every request is its own ``torch.zeros``.
+FX_ARENA_INT64 = 1 << 18          # 2 MiB (googleresnet's nine folded BatchNorms take 1.7 MiB)
+_fx = {"arena": None, "offset": 0, "owner": None, "eager": {}, "kept": []}
+
+
+def _fx_reset(owner):
+    _fx["arena"], _fx["offset"], _fx["owner"] = None, 0, owner
+
+
+def fx_take(channels, device):
+    "a zeroed int64 [8][5][channels][16] slot set (sgmcmc_fx_slot_int64) for one launch pair of this pass"
+    n = _hip.lib().sgmcmc_fx_slot_int64(channels)
+    if not _defer["active"] or n > FX_ARENA_INT64:
+        return torch.zeros(n, dtype=torch.int64, device=device)
+    if _fx["arena"] is None:
+        if torch.cuda.is_current_stream_capturing():
+            arena = torch.zeros(FX_ARENA_INT64, dtype=torch.int64, device=device)
+            # the graph replays on this memory: it lives as long as the model that owns the captured pass
+            owner = _fx["owner"]
+            (owner.__dict__.setdefault("_fx_arenas", []) if hasattr(owner, "__dict__") else _fx["kept"]).append(arena)
+        else:
+            key = (id(_fx["owner"]), torch.cuda.current_stream(device).cuda_stream, str(device))
+            arena = _fx["eager"].get(key)
+            if arena is None:
+                if len(_fx["eager"]) >= 16:
+                    _fx["eager"].clear()
+                arena = _fx["eager"][key] = torch.empty(FX_ARENA_INT64, dtype=torch.int64, device=device)
+            arena.zero_()
+        _fx["arena"], _fx["offset"] = arena, 0
+    if _fx["offset"] + n > FX_ARENA_INT64:
+        return torch.zeros(n, dtype=torch.int64, device=device)
+    out = _fx["arena"][_fx["offset"]:_fx["offset"] + n]
+    _fx["offset"] += n
+    return out
+
 
 @contextlib.contextmanager
 def deferring(owner=None):
@@ -119,6 +158,7 @@ def deferring(owner=None):
     _defer["active"] = True
     _defer["uses"] = {}
     _defer["weights"] = {}
+    _fx_reset(owner)
     _frag_valid.clear()
     _pending.clear()                # leftovers of a pass that raised before its final callback
     if PERSISTENT and owner is not None:
@@ -138,6 +178,7 @@ def deferring(owner=None):
         _defer["active"] = False
         _defer["uses"] = {}
         _defer["weights"] = {}
+        _fx_reset(None)
         _frag_valid.clear()
     _flush_pending()                # no-op when the backward's final callback already ran
 

@@ -95,6 +95,39 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
     return y, out, saved
 
 
+# The block's FIRST BatchNorm + ReLU folded into the second convolution's operand staging (round 3): conv1 leaves its
+# batch statistics in integer fx slots (csrc/conv_hip.inc: order-independent, hence bit-reproducible, atomics into per-XCD
+# slots), conv2 forms the BatchNorm's coefficients from them in its prologue, applies BatchNorm + ReLU to its operands
+# on their way into LDS and writes h as a side output -- three launches forward instead of four.  MEASURED, OFF BY
+# DEFAULT: 83 -> 77 launches (7 apply launches go, one zeroing launch comes) but the same 1,183 steps/s -- the two
+# convolutions get slower by what the apply launch cost (csrc/conv_hip.inc, BnIn).  SGMCMC_FOLD_BN=1 enables it (its
+# statistics, exact integer totals, differ from the per-slice pairs' combination in rounding; tested at both settings).
+FOLD_BN = os.environ.get("SGMCMC_FOLD_BN", "0") == "1"
+
+
+def _conv_bn_conv_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, s):
+    "y1 = conv3x3(x, w1); h = relu(bn1(y1)); y2 = conv3x3(h, w2) + y2's statistics -> y1, h, saved1, y2, stats2, slices"
+    n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+    y1, h, y2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    saved1 = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    fx = _conv.fx_take(c, x.device)
+    err = lib.sgmcmc_conv3x3_fx(x.data_ptr(), w1.data_ptr(), y1.data_ptr(), n, c, hw, fx.data_ptr(), s)
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_fx")
+    slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
+    stats2 = torch.empty((c, slices, 2), dtype=torch.float64, device=x.device)
+    slot = _bn.log_slot(rm1)
+    B = _hip.BnIn(fx=fx.data_ptr(), gamma=g1.data_ptr(), beta=b1.data_ptr(), save_mean=saved1[0].data_ptr(),
+                  save_invstd=saved1[1].data_ptr(), running_mean=0 if slot is not None else rm1.data_ptr(),
+                  running_var=0 if slot is not None else rv1.data_ptr(), stat_log=_p(slot), momentum=float(mom1),
+                  eps=float(eps1), h=h.data_ptr())
+    err = lib.sgmcmc_conv3x3_bnin(y1.data_ptr(), w2.data_ptr(), y2.data_ptr(), n, c, hw, stats2.data_ptr(),
+                                  ctypes.byref(B), s)
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_bnin")
+    return y1, h, saved1, y2, stats2, slices
+
+
 def _reduce_or_defer(lib, w, part, n_slabs, s):
     dw = torch.empty_like(w)
     if _conv._may_defer(w):      # summed with the pass's other slabs by ONE launch at its end
@@ -222,8 +255,18 @@ class _Block(torch.autograd.Function):
         _conv._note_use(w1, w2)
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         s = _stream()
-        y1, h, saved1 = _conv_bn_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, None, s)
-        y2, out, saved2 = _conv_bn_fwd(lib, h, w2, g2, b2, rm2, rv2, mom2, eps2, x, s)
+        if FOLD_BN and not _conv.PERSISTENT:
+            y1, h, saved1, y2, stats2, slices = _conv_bn_conv_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, s)
+            n, c, hw = x.shape[0], x.shape[1], x.shape[2]
+            out = torch.empty_like(x)
+            saved2 = torch.empty((2, c), dtype=torch.float32, device=x.device)
+            err = _bn.train_fwd(lib, y2, x, g2, b2, rm2, rv2, mom2, eps2, 1, n, c, hw * hw, out, saved2, None, stats2,
+                                slices, s)
+            if err:
+                _hip.check(err, "sgmcmc_bn_train_fwd")
+        else:
+            y1, h, saved1 = _conv_bn_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, None, s)
+            y2, out, saved2 = _conv_bn_fwd(lib, h, w2, g2, b2, rm2, rv2, mom2, eps2, x, s)
         ctx.save_for_backward(x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved)
         ctx.mark_non_differentiable(y2, saved2)
         ctx.set_materialize_grads(False)

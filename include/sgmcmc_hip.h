@@ -375,6 +375,29 @@ int sgmcmc_conv3x3_stat_slices(int n_img, int channels, int hw);
 int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int channels, int hw,
                    int transpose_w, double* stats, void* stream);
 
+/* A residual block's first BatchNorm + ReLU folded into its second convolution (models/google_resnet.py:34-43):
+ *   sgmcmc_conv3x3_fx    y = conv3x3(x, w) and the batch statistics of y ADDED to `fx` -- per-XCD integer slots,
+ *                        int64 [8][5][channels][16] (sgmcmc_fx_slot_int64(channels) elements), ZEROED by the caller:
+ *                        integer atomics commute, so the totals carry the same bits whatever ran where;
+ *   sgmcmc_conv3x3_bnin  y = conv3x3(relu(BatchNorm(x)), w): training-mode BatchNorm on the statistics in bn->fx and
+ *                        the ReLU applied while the operands are staged, bn->h <- relu(BatchNorm(x)) as a side output
+ *                        (the backward needs it), saved / running statistics (or the log slot) written as
+ *                        sgmcmc_bn_train_fwd[_log] does; `stats`: y's own statistics per slice as sgmcmc_conv3x3.
+ * The BatchNorm's apply launch and its read of x disappear. */
+typedef struct {
+  const int64_t* fx;
+  const float *gamma, *beta;
+  float *save_mean, *save_invstd, *running_mean, *running_var;
+  double* stat_log;
+  double momentum, eps;
+  float* h;
+} sgmcmc_bn_in;
+int64_t sgmcmc_fx_slot_int64(int channels);
+int sgmcmc_conv3x3_fx(const float* x, const float* w, float* y, int n_img, int channels, int hw, int64_t* fx,
+                      void* stream);
+int sgmcmc_conv3x3_bnin(const float* x, const float* w, float* y, int n_img, int channels, int hw, double* stats,
+                        const sgmcmc_bn_in* bn, void* stream);
+
 /* Weight gradient of the same convolution: dw[co,ci,r,s] = sum_{n,p} dy[n,co,p] x[n,ci,p+(r-1,s-1)].
  * `scratch` holds sgmcmc_conv3x3_wrw_scratch_floats(...) floats of per-workgroup partial slabs that a
  * second launch sums in a fixed order (deterministic; no atomics).  -1 / hipErrorInvalidValue for

@@ -71,12 +71,15 @@ def _route(monkeypatch, route):
 ROUTES = ["epilogue_sums", "fused", "two_launch"]
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
-def test_fused_block_matches_float64_reference(c, hw, n, route, monkeypatch):
+def test_fused_block_matches_float64_reference(c, hw, n, route, fold, monkeypatch):
+    "fold: the first BatchNorm + ReLU applied inside the second convolution's staging (statistics from integer fx slots)"
     from bnn_priors_amd import resblock
     _route(monkeypatch, route)
+    monkeypatch.setattr(resblock, "FOLD_BN", fold)
     blk = _block(c)
     blk.train()
     g = torch.Generator().manual_seed(100 * c + n)
@@ -98,11 +101,13 @@ def test_fused_block_matches_float64_reference(c, hw, n, route, monkeypatch):
         torch.testing.assert_close(grads[k].double(), ref_g[k], rtol=2e-3, atol=3e-4 * scale(ref_g[k])), k
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("route", ROUTES[:2])
 @pytest.mark.parametrize("c,hw", SHAPES)
-def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, route, monkeypatch):
+def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, route, fold, monkeypatch):
     from bnn_priors_amd import resblock
     _route(monkeypatch, route)
+    monkeypatch.setattr(resblock, "FOLD_BN", fold)
     g = torch.Generator().manual_seed(c)
     x = torch.relu(torch.randn(64, c, hw, hw, generator=g)).cuda()
     dout = torch.randn(64, c, hw, hw, generator=g).cuda()
@@ -219,3 +224,46 @@ def test_weight_gradients_on_a_side_stream_have_the_same_bits(monkeypatch):
         outs.append([p.grad.clone() for p in net.parameters()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("c,hw", SHAPES)
+def test_folded_first_batchnorm_logs_its_statistics_and_sums_exactly(c, hw, monkeypatch):
+    """the folded route in logging mode (the exact pass's lanes): the first BatchNorm's batch mean / unbiased variance
+    go to its slot, the running statistics stay; and the integer fx totals do not depend on the order of the atomics:
+    the saved statistics of two runs -- one of them with the OTHER half of the GPU kept busy by a second stream -- are
+    bit-identical"""
+    from bnn_priors_amd import bn as bnmod
+    from bnn_priors_amd import resblock
+    from bnn_priors_amd.models import nets
+    monkeypatch.setattr(resblock, "FOLD_BN", True)
+    g = torch.Generator().manual_seed(7 * c)
+    x = torch.relu(torch.randn(32, c, hw, hw, generator=g)).cuda()
+    blk = _block(c, seed=9)
+    blk.train()
+    bns = [m for m in blk.modules() if isinstance(m, nets._BatchNorm2d)]
+    slots = {id(m.running_mean): torch.zeros((c, 2), dtype=torch.float64, device="cuda") for m in bns}
+    before = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
+    with torch.no_grad(), bnmod.logging_running_stats(slots):
+        out_log = blk(x)
+    for m, (rm, rv) in zip(bns, before):
+        assert torch.equal(m.running_mean, rm) and torch.equal(m.running_var, rv)
+    with torch.no_grad():
+        out = blk(x)                                   # the same batch, running statistics advanced this time
+    assert torch.equal(out, out_log)
+    mom = bns[0].momentum
+    want_mean = (1 - mom) * before[0][0].double() + mom * slots[id(bns[0].running_mean)][:, 0]
+    want_var = (1 - mom) * before[0][1].double() + mom * slots[id(bns[0].running_mean)][:, 1]
+    assert torch.equal(bns[0].running_mean, want_mean.float()) and torch.equal(bns[0].running_var, want_var.float())
+    y1 = torch.nn.functional.conv2d(x.double(), blk.main[0].weight.double(), padding=1)
+    torch.testing.assert_close(slots[id(bns[0].running_mean)][:, 0], y1.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(slots[id(bns[0].running_mean)][:, 1], y1.var(dim=(0, 2, 3), unbiased=True), rtol=1e-5, atol=1e-6)
+    # a busy neighbour stream changes when and where workgroups run, not the sums
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device="cuda")
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                junk = junk @ junk * 1e-3
+        out2 = blk(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)                      # (training mode: the output does not depend on the running statistics)
