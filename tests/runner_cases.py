@@ -29,11 +29,48 @@ CASES.update({
                                             runner="HMCReject", model="googleresnet",
                                             weight_prior="student-t", n=128, batch=32, image=True),
 })
+# Runner options the reference exposes beyond the defaults of RUN_KW (round 4; ``run`` overrides RUN_KW per case):
+# the descent phase at T = 0 and thinning (inference.py:56-66,141-142), the ``stairs`` / ``flat`` schedules (:96-108),
+# ``precond_update`` None / k > 1 (:167; inference_reject.py:163 tests (epoch + 1) % k), ``data_mult`` (:72).
+CASES.update({
+    # 4 epochs per cycle = 1 descent (T = 0) + 1 warm-up + 2 sampling of which every 2nd is stored
+    "VerletSGLDReject_descent_skip2": dict(momentum=0.994, temperature=1.0, lr=0.01, reject_samples=True,
+                                           runner="VerletSGLDReject",
+                                           run=dict(epochs_per_cycle=4, warmup_epochs=1, sample_epochs=2, skip=2)),
+    "SGLD_descent_skip2": dict(momentum=0.9, temperature=1.0, lr=0.001, reject_samples=False, runner="SGLD",
+                               run=dict(epochs_per_cycle=4, warmup_epochs=1, sample_epochs=2, skip=2)),
+    # StepLR(150 * len(dataloader), 0.1): one minibatch per epoch, so the stair is reached at step 150 of 152
+    "VerletSGLD_stairs": dict(momentum=0.9, temperature=1.0, lr=0.01, reject_samples=True, runner="VerletSGLD",
+                              n=128, batch=128,
+                              run=dict(cycles=1, epochs_per_cycle=152, warmup_epochs=150, sample_epochs=2,
+                                       sampling_decay="stairs")),
+    "VerletSGLDReject_stairs": dict(momentum=0.994, temperature=1.0, lr=0.01, reject_samples=True,
+                                    runner="VerletSGLDReject", run=dict(sampling_decay=False)),
+    "SGLD_flat_noprecond": dict(momentum=0.9, temperature=1.0, lr=0.001, reject_samples=False, runner="SGLD",
+                                run=dict(sampling_decay="flat", precond_update=None)),
+    "VerletSGLDReject_noprecond": dict(momentum=0.994, temperature=1.0, lr=0.01, reject_samples=True,
+                                       runner="VerletSGLDReject", run=dict(precond_update=None)),
+    # preconditioner refreshed every 2nd epoch: after epochs 1, 3 of a cycle in the reject runners, 0, 2 in the plain ones
+    "VerletSGLDReject_precond2": dict(momentum=0.994, temperature=1.0, lr=0.01, reject_samples=True,
+                                      runner="VerletSGLDReject",
+                                      run=dict(epochs_per_cycle=4, warmup_epochs=2, sample_epochs=2, precond_update=2)),
+    "VerletSGLD_precond2": dict(momentum=0.9, temperature=1.0, lr=0.01, reject_samples=True, runner="VerletSGLD",
+                                run=dict(epochs_per_cycle=4, warmup_epochs=2, sample_epochs=2, precond_update=2)),
+    "VerletSGLD_datamult2": dict(momentum=0.9, temperature=1.0, lr=0.01, reject_samples=True, runner="VerletSGLD",
+                                 run=dict(data_mult=2.0)),
+    "VerletSGLDReject_datamult2": dict(momentum=0.994, temperature=1.0, lr=0.01, reject_samples=True,
+                                       runner="VerletSGLDReject", run=dict(data_mult=2.0)),
+})
 STREAMS_EXACT = ("acceptance/is_sample", "acceptance/rejected", "lr", "temperature")
 STREAMS_FLOAT = ("delta_energy", "total_energy", "est_temperature/all", "est_config_temp/all",
                  "potential", "log_prior", "loss", "acc", "test/loss", "test/acc")
 RUN_KW = dict(epochs_per_cycle=2, warmup_epochs=1, sample_epochs=1, skip=1, metrics_skip=10,
               cycles=2, precond_update=1, sampling_decay="cosine")
+
+
+def run_kw(cfg):
+    "RUN_KW with the case's ``run`` overrides"
+    return {**RUN_KW, **(cfg or {}).get("run", {})}
 
 
 def make_data(device="cpu", cfg=None):

@@ -110,7 +110,7 @@ def test_runner_host_logic_matches_reference_goldens(name):
         model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
         temperature=cfg["temperature"], momentum=cfg["momentum"],
         reject_samples=cfg["reject_samples"], metrics_saver=metrics, model_saver=None,
-        **RC.RUN_KW, **({"cycle_seed": RC.CYCLE_SEED} if "Reject" in name else {}))
+        **RC.run_kw(cfg), **({"cycle_seed": RC.CYCLE_SEED} if "Reject" in name else {}))
     runner.run()
     # same torch-CPU ops, same noise: near bit equality on the host that generated the goldens; float32 CPU kernels
     # round differently on another instruction set (AVX-512 vs AVX2), so the tolerance is one that holds across hosts
@@ -133,7 +133,7 @@ def test_runner_on_gpu_matches_reference_goldens(name):
         model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
         temperature=cfg["temperature"], momentum=cfg["momentum"],
         reject_samples=cfg["reject_samples"], metrics_saver=metrics, model_saver=None,
-        seed=RC.SEED, chain_id=0, **RC.RUN_KW,
+        seed=RC.SEED, chain_id=0, **RC.run_kw(cfg),
         **({"cycle_seed": RC.CYCLE_SEED} if "Reject" in name else {}))
     runner.run()
     # accept/reject flags, step indices, lr and temperature streams are compared exactly
