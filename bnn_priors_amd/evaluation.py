@@ -17,6 +17,7 @@ import contextlib
 import math
 import os
 import warnings
+import weakref
 
 import torch
 
@@ -165,13 +166,21 @@ class _GraphedLogits:
         return self.out
 
 
+# model -> {key: _GraphedLogits}.  Kept OUTSIDE the module (a hipGraph is neither picklable nor deep-copyable: a cache
+# in model.__dict__ broke copy.deepcopy(model) / torch.save(model) after the first evaluation) and weakly keyed, so the
+# graphs and their private memory pools go when the model goes.
+_eval_graphs = weakref.WeakKeyDictionary()
+
+
 def _logits_fn(model, x):
     "model.net(x), through a captured graph when the model is on the GPU in eval mode (cached per batch shape)"
     if not (EVAL_GRAPH and x.is_cuda and not model.training and not torch.is_grad_enabled()):
         return model.net(x)
-    cache = model.__dict__.setdefault("_eval_graphs", {})
-    # (the capture holds the parameters' storage addresses: a model moved or re-built since gets a new one)
-    key = (tuple(x.shape), x.dtype, tuple(p.data_ptr() for p in model.parameters()))
+    cache = _eval_graphs.setdefault(model, {})
+    # (the capture holds the storage addresses of the parameters AND of the buffers -- the running statistics the
+    # BatchNorm kernels read: a model moved, re-built or given re-registered buffers since gets a new capture)
+    key = (tuple(x.shape), x.dtype, tuple(p.data_ptr() for p in model.parameters()),
+           tuple(b.data_ptr() for b in model.buffers()))
     g = cache.get(key)
     if g is None:
         if len(cache) >= 4:

@@ -88,3 +88,30 @@ def test_evaluating_several_batches_per_forward_gives_the_same_rows(name, monkey
         tables[rows] = (lps.clone(), acc.clone())
     for rows in (96, 1024):
         assert torch.equal(tables[rows][0], tables[0][0]) and torch.equal(tables[rows][1], tables[0][1]), rows
+
+
+@pytest.mark.gpu
+def test_a_model_can_be_copied_and_pickled_after_evaluation_and_new_buffers_get_a_new_capture():
+    """the captured evaluation forwards live outside the module (a hipGraph is not picklable): deepcopy / torch.save of
+    an evaluated model work, and a re-registered BatchNorm buffer is not replayed from the old capture's address"""
+    import copy
+    import io
+    net, loader, samples, y = _setup("googleresnet", n=64, E=1, device="cuda:0")
+    lps0, acc0, _, _ = ev.predictive_tables(net, loader, samples)
+    assert ev._eval_graphs.get(net)                                  # a capture exists ...
+    assert "_eval_graphs" not in net.__dict__                        # ... and not inside the module
+    twin = copy.deepcopy(net)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    lps1, _, _, _ = ev.predictive_tables(twin, loader, samples)
+    assert torch.equal(lps0, lps1)
+    # a fresh running_var tensor (another storage): the key changes, the result follows the new statistics
+    bn = next(m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    n_before = len(ev._eval_graphs[net])
+    bn.running_var = bn.running_var.clone() * 4.0
+    one = dict(samples)
+    first = next(k for k in net.state_dict() if k.endswith("running_var"))     # (module order = state_dict order)
+    one[first] = samples[first] * 4.0
+    lps2, _, _, _ = ev.predictive_tables(net, loader, one)
+    assert len(ev._eval_graphs[net]) == n_before + 1
+    assert not torch.equal(lps0, lps2)
