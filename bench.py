@@ -216,13 +216,13 @@ def conv_rooflines(device, n_img=128, iters=60):
         slabs = ctypes.c_int(0)
         flop1 = 2.0 * n_img * hw * hw * c * c * 9
         out = torch.relu(torch.randn((n_img, c, hw, hw), generator=g, device=device))
-        sums = torch.zeros(lib.sgmcmc_bn_scratch_doubles(n_img, c, hw * hw), dtype=torch.float64, device=device)
+        sums = torch.zeros(lib.sgmcmc_bn_scratch_doubles(n_img, c, hw * hw, 1), dtype=torch.float64, device=device)
         saved = torch.stack([torch.zeros(c, device=device), torch.ones(c, device=device)])
         gamma, dgb = torch.ones(c, device=device), torch.empty((2, c), device=device)
         n_sums = ctypes.c_int(0)
         _hip.check(lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
                                           saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n_img, c,
-                                          hw * hw, stream), "sgmcmc_bn_bwd_sums")
+                                          hw * hw, 1, stream), "sgmcmc_bn_bwd_sums")
         A = _hip.ConvBnBwdArgs(dout=dy.data_ptr(), mask_out=out.data_ptr(), y=y.data_ptr(), mean=saved[0].data_ptr(),
                                invstd=saved[1].data_ptr(), gamma=gamma.data_ptr(), sums=sums.data_ptr(),
                                n_sums=n_sums.value, reserved=0, dgamma=dgb[0].data_ptr(), dbeta=dgb[1].data_ptr(),
@@ -251,11 +251,12 @@ def conv_rooflines(device, n_img=128, iters=60):
                                                  ctypes.byref(A), n_img, c, hw, ctypes.byref(slabs), stream),
                        "sgmcmc_conv3x3_bn_bwd")
         # (the down-sampling block's second convolution has no identity-shortcut block around it: plain route)
-        for name, fn, flops, per_step in (
-                (f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1, n_convs),
-                (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1, 0),
-                (f"conv::conv3x3_bwd_kernel<{c},{hw},8,SUMS>", bwd_sums, 2 * flop1, n_convs if not fused_route else 1),
-                (f"conv::fused_bwd_kernel<{c},{hw},8>", bn_bwd, 2 * flop1, n_convs - 1 if fused_route else 0)):
+        table = [(f"conv::conv3x3_kernel<{c},{hw},8,stats>", fwd, flop1, n_convs),
+                 (f"conv::conv3x3_bwd_kernel<{c},{hw},8>", bwd, 2 * flop1, 0),
+                 (f"conv::conv3x3_bwd_kernel<{c},{hw},8,SUMS>", bwd_sums, 2 * flop1, n_convs if not fused_route else 1)]
+        if _hip.ALTERNATIVES:       # (a measured alternative: only in a library built with SGMCMC_ALTERNATIVES=1)
+            table.append((f"conv::fused_bwd_kernel<{c},{hw},8>", bn_bwd, 2 * flop1, n_convs - 1 if fused_route else 0))
+        for name, fn, flops, per_step in table:
             for _ in range(5):
                 fn()
             torch.cuda.synchronize(device)
@@ -332,8 +333,8 @@ def bn_rooflines(device, n_img=128, iters=60):
         def bwd_dx():
             _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(),
                                             saved[0].data_ptr(), saved[1].data_ptr(), 1, n_img, c, hw * hw,
-                                            partial.data_ptr(), slices, dy.data_ptr(), 0, dgb[0].data_ptr(),
-                                            dgb[1].data_ptr(), None, stream), "sgmcmc_bn_bwd_dx")
+                                            partial.data_ptr(), slices, dy.data_ptr(), 0, dgb.data_ptr(), None, 1,
+                                            stream), "sgmcmc_bn_bwd_dx")
         for name, fn, nbytes, per_step in (
                 (f"bn::apply_kernel<relu> {c}@{hw}^2", lambda: apply(None), 8 * elems, (n_convs + 1) // 2 + (1 if c == 16 else 0)),
                 (f"bn::apply_kernel<relu,residual> {c}@{hw}^2", lambda: apply(res), 12 * elems, n_convs // 2 + (1 if c > 16 else 0)),

@@ -13,13 +13,18 @@ import numpy as np
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip.so")
+# SGMCMC_ALTERNATIVES=1: the library that ALSO carries the measured alternatives (include/sgmcmc_hip_alternatives.h:
+# persistent convolutions, folded BatchNorm, fused BatchNorm backward, side-stream weight gradients) -- a separate file,
+# so the shipped library never contains them; the switches that select them (conv.PERSISTENT, resblock.FOLD_BN, ...)
+# refuse to turn on without it.
+ALTERNATIVES = os.environ.get("SGMCMC_ALTERNATIVES", "0") == "1"
+LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip_alt.so" if ALTERNATIVES else "libsgmcmc_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 # one translation unit: sgmcmc_hip.hip #includes mlp_hip.inc (they share the finalize body)
 SOURCES = [os.path.join(_HERE, "csrc", "sgmcmc_hip.hip")]
 SOURCE = SOURCES[0]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CHUNK = 4096
 CHUNK_SMALL = 1024
 NSUMS = 6
@@ -85,7 +90,8 @@ class ReduceJob(ctypes.Structure):
 
 class ConvBwdEpilogue(ctypes.Structure):
     "sgmcmc_conv_bwd_epilogue"
-    _fields_ = [(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
+                + [("group_imgs", ctypes.c_int32), ("reserved", ctypes.c_int32)])
 
 
 class BnResidualSums(ctypes.Structure):
@@ -98,7 +104,8 @@ class BnDual(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_void_p) for n in ("r", "gamma", "beta", "partial")]
                 + [("n_partials", ctypes.c_int32), ("reserved", ctypes.c_int32), ("eps", ctypes.c_double),
                    ("momentum", ctypes.c_double)]
-                + [(n, ctypes.c_void_p) for n in ("save_mean", "save_invstd", "running_mean", "running_var", "stat_log")])
+                + [(n, ctypes.c_void_p) for n in ("save_mean", "save_invstd", "running_mean", "running_var", "stat_log")]
+                + [("log_stride", ctypes.c_int64)])
 
 
 class BnIn(ctypes.Structure):
@@ -209,21 +216,19 @@ EXPORTS = {
     "sgmcmc_conv3x3_wrw_scratch_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sgmcmc_conv3x3_wrw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sgmcmc_bn_scratch_doubles": (ctypes.c_int64, [ctypes.c_int] * 4),
     "sgmcmc_bn_train_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_double]
-                            + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
-    "sgmcmc_fx_slot_int64": (ctypes.c_int64, [ctypes.c_int]),
-    "sgmcmc_conv3x3_fx": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
-    "sgmcmc_conv3x3_bnin": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
-                            + [ctypes.c_void_p, ctypes.POINTER(BnIn), ctypes.c_void_p]),
+                            + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_train_fwd_dual": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double, ctypes.c_double]
-                                 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p,
-                                                                                 ctypes.POINTER(BnDual), ctypes.c_void_p]),
-    "sgmcmc_bn_train_fwd_log": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_double] + [ctypes.c_int] * 4
-                                + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]),
+                                 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+                                 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(BnDual), ctypes.c_int,
+                                    ctypes.c_void_p]),
+    "sgmcmc_bn_train_fwd_log": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_double] + [ctypes.c_int] * 4
+                                + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_running_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6),
+    "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4
+                            + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
                            + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_wrw_reduce_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -240,9 +245,10 @@ EXPORTS = {
     "sgmcmc_bias_relu_pool_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_bias_relu_pool_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_linear_fwd_loss": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p]),
-    "sgmcmc_pool_linear_loss": (ctypes.c_int, [ctypes.c_void_p] * 17 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
+    "sgmcmc_pool_linear_loss": (ctypes.c_int, [ctypes.c_void_p] * 16 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5
+                                + [ctypes.c_float, ctypes.c_void_p]),
     "sgmcmc_pool_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "sgmcmc_pool_linear_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 11 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "sgmcmc_pool_linear_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 11 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "sgmcmc_pool_linear_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "sgmcmc_linear_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "sgmcmc_linear_row_groups": (ctypes.c_int, [ctypes.c_int]),
@@ -255,27 +261,17 @@ EXPORTS = {
                                + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
                               + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
-    "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
-                                + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_sum_slices": (ctypes.c_int, [ctypes.c_int] * 3),
     "sgmcmc_bn_eval_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_double] + [ctypes.c_int] * 4
                            + [ctypes.c_void_p, ctypes.c_void_p]),
-    "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
-    "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
-    "sgmcmc_conv3x3_frag_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2),
-    "sgmcmc_conv3x3_frag_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
-                                + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv_down_bwd_ex": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ConvBwdEpilogue)]
                                 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_bn_bwd_dx": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
-                         + [ctypes.c_void_p] * 4 + [ctypes.POINTER(BnResidualSums), ctypes.c_void_p]),
+                         + [ctypes.c_void_p] * 3 + [ctypes.POINTER(BnResidualSums), ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
-    "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 3
+    "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 4
                            + [ctypes.c_void_p]),
-    "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
-                              + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv50": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv50_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv50_bwd_t": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int),
@@ -303,6 +299,26 @@ EXPORTS = {
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),
 }
+
+# include/sgmcmc_hip_alternatives.h (libsgmcmc_hip_alt.so only)
+ALT_EXPORTS = {
+    "sgmcmc_fx_slot_int64": (ctypes.c_int64, [ctypes.c_int]),
+    "sgmcmc_conv3x3_fx": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bnin": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
+                            + [ctypes.c_void_p, ctypes.POINTER(BnIn), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
+                                + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2),
+    "sgmcmc_conv3x3_frag_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
+                                + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
+                              + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+}
+if ALTERNATIVES:
+    EXPORTS.update(ALT_EXPORTS)
 
 _lib = None
 
@@ -341,8 +357,8 @@ def build(verbose=False):
     """hipcc cross-compile for gfx950 (works without a GPU)."""
     import subprocess
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-I", os.path.join(_HERE, "csrc"), *SOURCES,
-           "-o", LIB_PATH]
+    cmd = ["hipcc", *HIPCC_FLAGS, *(["-DSGMCMC_ALTERNATIVES"] if ALTERNATIVES else []), "-I", INCLUDE_DIR,
+           "-I", os.path.join(_HERE, "csrc"), *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -29,12 +29,19 @@ class RandomCropFlip:
         self.pad, self.flip, self.seed, self.stream = int(pad), bool(flip), int(seed), int(stream)
         self.fill = None if fill is None else torch.as_tensor(fill, dtype=torch.float32).reshape(-1)
 
-    def gather(self, data, idx, draw):
-        "data [N, C, H, W] float32 on the GPU, idx int64 [B] on the same device -> augmented [B, C, H, W]"
+    def gather(self, data, idx, draw, out=None):
+        """data [N, C, H, W] float32 on the GPU, idx int64 [B] on the same device -> augmented [B, C, H, W]
+        (``out``: a contiguous float32 [B, C, H, W] tensor to write instead of a new one -- e.g. a slice of a captured
+        graph's static input: no staging copy)"""
         if not data.is_cuda or data.dtype != torch.float32 or data.dim() != 4 or not data.is_contiguous():
             raise ValueError("augmentation needs a contiguous float32 [N, C, H, W] tensor on the GPU")
         idx = idx.to(device=data.device, dtype=torch.int64).contiguous()
-        out = torch.empty((idx.numel(),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
+        shape = (idx.numel(),) + tuple(data.shape[1:])
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=data.device)
+        elif (tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != data.device
+              or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 tensor of the gathered batch's shape on the data's device")
         if idx.numel() == 0:
             return out
         fill = 0

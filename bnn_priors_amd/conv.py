@@ -53,6 +53,9 @@ DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
 # fragment launch, twice the slab bytes at 64 channels, twice the statistics slices for the BatchNorm kernels) --
 # DESIGN.md section 3.  SGMCMC_CONV_PERSISTENT=1 selects them (same results up to fp32 summation order: tested).
 PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "0") == "1"
+if PERSISTENT and not _hip.ALTERNATIVES:
+    raise RuntimeError("SGMCMC_CONV_PERSISTENT=1 selects a measured alternative: build and load the library with "
+                       "SGMCMC_ALTERNATIVES=1")
 
 # ---- prepared weight fragments (csrc/conv2_hip.inc) ------------------------------------------------------------
 # The persistent kernels read a convolution's weights in MFMA fragment order (forward, and transposed + flipped for
@@ -299,6 +302,15 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
     return dx, dw, partial, n_part
 
 
+def _group_imgs(n):
+    "images per group for a launch that looks a BatchNorm's saved statistics up by image (bn.grouped); 0: one batch"
+    from . import bn as _bn
+    G = _bn.groups()
+    if G > 1 and (PERSISTENT or SIDE_STREAM):
+        raise RuntimeError("bn.grouped(G > 1) runs on the default kernels only (no measured alternative)")
+    return n // G if G > 1 else 0
+
+
 def _both_grads(x, w, dy, defer, sums_for=None):
     "``sums_for`` = (y_bn, out_bn, saved_bn) of the BatchNorm + ReLU that produced x: its backward sums ride along"
     lib = _hip.lib()
@@ -333,7 +345,8 @@ def _both_grads(x, w, dy, defer, sums_for=None):
         n_part = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
         partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
         E = _hip.ConvBwdEpilogue(s_y=y_bn.data_ptr(), s_out=out_bn.data_ptr(), s_mean=saved_bn[0].data_ptr(),
-                                 s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr())
+                                 s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr(),
+                                 group_imgs=_group_imgs(n))
         err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
                                         dw.data_ptr(), scratch.data_ptr(), n, c, hw,
                                         ctypes.byref(slabs) if defer else None, _stream())
@@ -363,6 +376,9 @@ _pending = []
 # 1,137 -> 845 steps/s.  The merged launch (both halves' workgroups in one grid) stays the default;
 # SGMCMC_CONV_SIDE_STREAM=1 enables this route (same workgroups, same bits: tested).
 SIDE_STREAM = os.environ.get("SGMCMC_CONV_SIDE_STREAM", "0") == "1"
+if SIDE_STREAM and not _hip.ALTERNATIVES:
+    raise RuntimeError("SGMCMC_CONV_SIDE_STREAM=1 selects a measured alternative: build and load the library with "
+                       "SGMCMC_ALTERNATIVES=1")
 _side = {"streams": {}, "forked": None, "keep": []}
 
 
@@ -510,7 +526,8 @@ class _ConvDown(torch.autograd.Function):
             n_part = lib.sgmcmc_conv_down_bwd_sum_slices(n, c, hw)
             partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
             E = _hip.ConvBwdEpilogue(s_y=src_y.data_ptr(), s_out=x.data_ptr(), s_mean=src_saved[0].data_ptr(),
-                                     s_invstd=src_saved[1].data_ptr(), s_partial=partial.data_ptr())
+                                     s_invstd=src_saved[1].data_ptr(), s_partial=partial.data_ptr(),
+                                     group_imgs=_group_imgs(n))
             err = lib.sgmcmc_conv_down_bwd_ex(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
                                               dys.data_ptr(), dx.data_ptr(), ctypes.byref(E), dwm.data_ptr(),
                                               dws.data_ptr(), scratch.data_ptr(), n, c, hw,

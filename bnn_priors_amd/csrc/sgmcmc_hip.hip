@@ -1283,8 +1283,8 @@ int sgmcmc_step_indirect_parts(const sgmcmc_layout* L, const sgmcmc_step_args* A
   return (int)hipGetLastError();
 }
 
-// by-value variant used by sgmcmc_dense_step_direct (csrc/mlp_hip.inc)
-int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
+// by-value variant used by sgmcmc_dense_step_direct (csrc/mlp_hip.inc); internal: not part of the C ABI
+__attribute__((visibility("hidden"))) int sgmcmc_step_parts_value(const sgmcmc_layout* L, const sgmcmc_step_args* A,
                             const sgmcmc_grad_parts* P, void* stream) {
   if (!P || !P->gpart || P->n_slices <= 0 || P->batch <= 0 || !(P->num_data > 0))
     return (int)hipErrorInvalidValue;
@@ -1461,10 +1461,20 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "mlp_hip.inc"
 // the convolutional trunk's fp32-MFMA kernels (googleresnet gradient)
 #include "conv_hip.inc"
-#include "conv2_hip.inc"
 #include "conv_down_hip.inc"
 #include "conv50_hip.inc"
 #include "bn_hip.inc"
+// Measured alternatives that LOST to the default kernels inside the captured step (the persistent
+// convolutions on prepared weight fragments, the BatchNorm folded into the next convolution's staging, the BatchNorm
+// backward formed inside the convolution-gradient launch, the weight-gradient half on a side stream).  They are kept,
+// tested and switchable -- but only in a library built with -DSGMCMC_ALTERNATIVES (include/sgmcmc_hip_alternatives.h;
+// SGMCMC_ALTERNATIVES=1 in the environment of bnn_priors_amd._hip.build()): the shipped library and the header a
+// maintainer reads describe the path that runs.
+#ifdef SGMCMC_ALTERNATIVES
+#include "sgmcmc_hip_alternatives.h"
+#include "conv2_hip.inc"
 #include "conv_fused_hip.inc"
+#include "conv_fold_hip.inc"
+#endif
 #include "pool_hip.inc"
 #include "augment_hip.inc"

@@ -285,25 +285,43 @@ class GraphedAccumulate:
     device scalar.  An epoch-long pass is then L graph launches and no host read-back;
     off-shape batches (the ragged last one) run the same ops eagerly into the same accumulators.
     BatchNorm nets update their running statistics on every replay exactly as the eager pass does;
-    the capture's warm-up runs are undone from a snapshot of the model's buffers."""
+    the capture's warm-up runs are undone from a snapshot of the model's buffers.
 
-    def __init__(self, potential, optimizer, x_example, y_example, warmup=2, log_slots=None):
-        """``log_slots`` (id(running_mean) -> float64 [C, 2] tensor): the BatchNorm layers leave their batch statistics
-        there instead of advancing their running statistics (bn.logging_running_stats) -- for a lane of
-        ``ConcurrentAccumulate``, which advances them afterwards in batch order."""
+    ``group`` = G > 1 (round 4): the static inputs hold G minibatches one after the other and ONE replay evaluates all
+    of them -- every launch of the chain carries G times the work above the same launch floor.  Training-mode BatchNorm
+    statistics stay per minibatch (``bn.grouped``: the reference computes them per minibatch, models/google_resnet.py:
+    14-27 under inference_reject.py:18-33); the convolutions, the head and the loss are per image; the groups'
+    weight-gradient slabs and (dgamma, dbeta) rows are summed by the pass's one deferred reduction.  Needs ``log_slots``
+    (the groups' running-statistics updates are ordered: they are logged and replayed, ``ConcurrentAccumulate``)."""
+
+    def __init__(self, potential, optimizer, x_example, y_example, warmup=2, log_slots=None, group=1, share=None):
+        """``log_slots`` (id(running_mean) -> float64 [C, 2] tensor; [G, C, 2] with ``group`` = G > 1): the BatchNorm
+        layers leave their batch statistics there instead of advancing their running statistics
+        (bn.logging_running_stats) -- for a lane of ``ConcurrentAccumulate``, which advances them afterwards in batch
+        order.  ``share``: another GraphedAccumulate whose accumulators (grads, loss) this one adds to."""
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.model = potential.model
-        self.log_slots = log_slots
+        self.log_slots, self.group = log_slots, int(group)
+        if self.group > 1 and log_slots is None and any(
+                isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats for m in self.model.modules()):
+            raise _bn.LogModeUnsupported("a grouped accumulate body needs logged BatchNorm statistics")
         dev = self.eng.device
-        self.x = torch.empty_like(x_example, device=dev)
-        self.y = torch.empty_like(y_example, device=dev)
-        self.shape = (tuple(self.x.shape), tuple(self.y.shape))
-        self.loss = torch.zeros((), dtype=torch.float64, device=dev)
-        self.grads = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.eng.params]
-        self.x.copy_(x_example)
-        self.y.copy_(y_example)
+        self.rows = x_example.shape[0]
+        rep = lambda t: t.repeat((self.group,) + (1,) * (t.dim() - 1)) if self.group > 1 else t
+        self.x = torch.empty_like(rep(x_example), device=dev)
+        self.y = torch.empty_like(rep(y_example), device=dev)
+        self.shape = (tuple(x_example.shape), tuple(y_example.shape))      # of ONE minibatch
+        if share is None:
+            self.loss = torch.zeros((), dtype=torch.float64, device=dev)
+            self.grads = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.eng.params]
+        else:
+            self.loss, self.grads = share.loss, share.grads
+        self.x.copy_(rep(x_example))
+        self.y.copy_(rep(y_example))
         buffers = {k: v.clone() for k, v in self.model.state_dict().items()}
-        self.begin()
+        keep = ([g.clone() for g in self.grads], self.loss.clone()) if share is not None else None
+        if share is None:
+            self.begin()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -317,19 +335,23 @@ class GraphedAccumulate:
         with torch.no_grad():
             for k, v in self.model.state_dict().items():
                 v.copy_(buffers[k])
+            if keep is not None:        # (the warm-up runs added to accumulators that are somebody else's)
+                for g, k in zip(self.grads, keep[0]):
+                    g.copy_(k)
+                self.loss.copy_(keep[1])
         torch.cuda.synchronize(dev)
 
     def _logging(self):
         return _bn.logging_running_stats(self.log_slots) if self.log_slots is not None else contextlib.nullcontext()
 
-    def _accumulate(self, x, y):
+    def _accumulate(self, x, y, group=1):
         # every batch's gradient lands in FRESH tensors (autograd adopts them: no per-tensor `grad += ...`
         # launches, and the convolution slabs take their one deferred reduction), then ONE multi-tensor add
         # folds them into the accumulators
         params = self.eng.params
         for p in params:
             p.grad = None
-        with self._logging(), _conv.deferring(self.model):
+        with self._logging(), _bn.grouped(group), _conv.deferring(self.model):
             with _pool.head_loss(y, "sum", self.pot.N):
                 f = self.pot._logits(x)
             this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.pot.N)
@@ -338,7 +360,7 @@ class GraphedAccumulate:
         self.loss += this.detach().double()
 
     def _body(self):
-        self._accumulate(self.x, self.y)
+        self._accumulate(self.x, self.y, self.group)
 
     def matches(self, x, y):
         return (tuple(x.shape), tuple(y.shape)) == self.shape
@@ -353,8 +375,20 @@ class GraphedAccumulate:
         for p, g in zip(self.eng.params, self.grads):
             p.grad = g
 
+    def slot(self, j):
+        "the static inputs of minibatch j of the group: (x [B, ...], y [B]) views to be filled by the producer"
+        return self.x[j * self.rows:(j + 1) * self.rows], self.y[j * self.rows:(j + 1) * self.rows]
+
+    def owns(self, x, y, j=0):
+        "x, y ARE slot j (a producer that filled them in place: nothing to stage)"
+        xs, ys = self.slot(j)
+        return (x.data_ptr() == xs.data_ptr() and y.data_ptr() == ys.data_ptr() and x.shape == xs.shape
+                and x.is_contiguous() and y.is_contiguous())
+
     def add(self, x, y):
-        stage_batch(self.x, x, self.y, y)
+        "one minibatch through a group-of-one body"
+        if not self.owns(x, y):
+            stage_batch(self.x, x, self.y, y)
         self.graph.replay()
 
     def add_eager(self, x, y):
@@ -364,24 +398,29 @@ class GraphedAccumulate:
 
 # ------------------------------------------------------------------ the exact pass on several streams
 EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "2"))
+EXACT_GROUP = int(os.environ.get("SGMCMC_EXACT_GROUP", "4"))      # minibatches per launch chain (1: one, as round 3)
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
 
 class ConcurrentAccumulate:
-    """The exact full-data gradient with its minibatches evaluated on ``lanes`` HIP streams at once: every lane is a
-    ``GraphedAccumulate`` with its own captured body, static inputs and accumulators; minibatch j goes to lane
-    j mod lanes.  A gradient evaluation is a chain of ~90 dependent launches that leaves the GPU partly idle at
-    every boundary; two independent chains interleave (1.36x one chain's throughput for googleresnet, 1.42x for the
-    convolutional classifier).  The minibatches of this pass are independent given the parameters
-    (inference_reject.py:18-33) -- except that training-mode BatchNorm advances its running statistics batch by batch:
-    the lanes therefore LOG every layer's batch mean / unbiased variance (``bn.logging_running_stats``) and the
-    running statistics are advanced afterwards from the log in minibatch order, with the arithmetic of the in-kernel
-    update (same bits as the sequential pass); ``num_batches_tracked`` is advanced by the number of minibatches.
+    """The exact full-data gradient with its minibatches evaluated on ``lanes`` HIP streams at once, ``group`` of them
+    per launch chain: every lane owns a grouped ``GraphedAccumulate`` (G minibatches per replay) and a single one (what
+    is left over when the pass's full-size minibatches are not a multiple of G), with their own static inputs and ONE set
+    of accumulators per lane; group q goes to lane q mod lanes.  A gradient evaluation is a chain of ~90 dependent
+    launches at the launch floor that leaves the GPU partly idle at every boundary: G minibatches per launch put G times
+    the work above the same floor, and two independent chains interleave.  The minibatches of this pass are independent
+    given the parameters (inference_reject.py:18-33) -- except that training-mode BatchNorm advances its running
+    statistics batch by batch: the bodies therefore LOG every layer's batch mean / unbiased variance per minibatch
+    (``bn.logging_running_stats``, ``bn.grouped``) and the running statistics are advanced afterwards from the log in
+    minibatch order, with the arithmetic of the in-kernel update (same bits as the sequential pass);
+    ``num_batches_tracked`` is advanced by the number of minibatches.
     The gradient is the sum of the lanes' accumulators (a fixed order: reproducible; the sequential pass adds the
     minibatches in another order, so the two agree to rounding, not bit for bit).  Off-shape minibatches (the ragged
-    last one) are evaluated eagerly, in order, after the lanes have been joined."""
+    last one) are evaluated eagerly, in order, after the lanes have been joined.
+    A batch source that can fill buffers in place (``_BatchSource.filling``) writes every minibatch straight into the
+    static inputs of the body that evaluates it: no staging copy."""
 
-    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=None):
+    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=None, group=None):
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.model = potential.model
         dev = self.dev = self.eng.device
@@ -391,62 +430,112 @@ class ConcurrentAccumulate:
             raise _bn.LogModeUnsupported("cumulative-average BatchNorm")
         self.cmax = max([m.num_features for m in self.bn_layers], default=1)
         self.n_bn = len(self.bn_layers)
+        G = EXACT_GROUP if group is None else int(group)
+        rows = x_example.shape[0]
+        while G > 1 and G * rows > 1024:       # (the fused head + loss launch takes up to 1,024 rows)
+            G -= 1
+        self.group = G = max(G, 1)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        self.lanes, self.log_cur = [], []
+        self.lanes, self.singles, self.log_cur, self.log_cur1 = [], [], [], []
         main = torch.cuda.current_stream(dev)
+        nb, cm = max(self.n_bn, 1), self.cmax
         for s in self.streams:
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                cur = torch.zeros((max(self.n_bn, 1), self.cmax, 2), dtype=torch.float64, device=dev)
-                slots = {id(m.running_mean): cur[i, :m.num_features] for i, m in enumerate(self.bn_layers)}
-                self.lanes.append(GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots))
-                self.log_cur.append(cur)
+                cur1 = torch.zeros((nb, cm, 2), dtype=torch.float64, device=dev)
+                slots1 = {id(m.running_mean): cur1[i, :m.num_features] for i, m in enumerate(self.bn_layers)}
+                single = GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots1)
+                self.singles.append(single)
+                self.log_cur1.append(cur1)
+                if G > 1:
+                    cur = torch.zeros((G, nb, cm, 2), dtype=torch.float64, device=dev)
+                    slots = {id(m.running_mean): cur[:, i, :m.num_features] for i, m in enumerate(self.bn_layers)}
+                    self.lanes.append(GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots,
+                                                        group=G, share=single))
+                    self.log_cur.append(cur)
             main.wait_stream(s)
-        self.log_all = torch.zeros((capacity or LOG_CAPACITY,) + tuple(self.log_cur[0].shape), dtype=torch.float64,
-                                   device=dev)
-        self.loss = self.lanes[0].loss
+        # (a group's minibatches are logged together: the log holds at least one group)
+        self.log_all = torch.zeros((max(capacity or LOG_CAPACITY, G), nb, cm, 2), dtype=torch.float64, device=dev)
+        self.loss = self.singles[0].loss
         self.count = self.logged_from = 0
 
     def matches(self, x, y):
-        return self.lanes[0].matches(x, y)
+        return self.singles[0].matches(x, y)
 
     def begin(self):
         main = torch.cuda.current_stream(self.dev)
-        for s, lane in zip(self.streams, self.lanes):
+        for s, lane in zip(self.streams, self.singles):
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 lane.begin()
         self.count = self.logged_from = 0
 
+    def _room(self, n):
+        "make sure the log takes n more minibatches"
+        if self.count - self.logged_from + n > self.log_all.shape[0]:      # the log is full: advance and start over
+            self._join_and_replay()
+
     def run(self, batches):
         "every minibatch of ``batches`` (an iterable of (x, y)), fetched under the stream of the lane that evaluates it"
-        it = iter(batches)
-        while True:
-            if self.count - self.logged_from >= self.log_all.shape[0]:      # the log is full: advance and start over
-                self._join_and_replay()
-            k = self.count % len(self.lanes)
-            with torch.cuda.stream(self.streams[k]):
-                try:
-                    x, y = next(it)
-                except StopIteration:
-                    break
-                if self.matches(x, y):
-                    self.lanes[k].add(x, y)
+        G, n_lanes = self.group, len(self.streams)
+        n_full = batches.n_full_batches() if hasattr(batches, "n_full_batches") else None
+        n_groups = n_full // G if (G > 1 and n_full is not None) else 0
+        target = {"dst": None}
+        filling = batches.filling(lambda rows: target["dst"](rows) if target["dst"] else None) \
+            if hasattr(batches, "filling") else contextlib.nullcontext()
+        with filling:
+            it = iter(batches)
+            turn = 0
+            # ---- whole groups: G minibatches per replay, written straight into the lane's static inputs
+            for q in range(n_groups):
+                k = turn % n_lanes
+                turn += 1
+                lane = self.lanes[k]
+                self._room(G)
+                with torch.cuda.stream(self.streams[k]):
+                    for j in range(G):
+                        target["dst"] = lambda rows, j=j: lane.slot(j) if rows == lane.rows else None
+                        x, y = next(it)
+                        if not lane.owns(x, y, j):
+                            xs, ys = lane.slot(j)
+                            stage_batch(xs, x, ys, y)
+                    target["dst"] = None
+                    lane.graph.replay()
                     if self.n_bn:
-                        self.log_all[self.count - self.logged_from].copy_(self.log_cur[k], non_blocking=True)
-                    self.count += 1
-                    continue
-            # an off-shape minibatch: in order, on the main stream, with the ordinary running-statistics update
-            self._join_and_replay()
-            x, y = x.to(self.dev), y.to(self.dev)
-            torch.cuda.current_stream(self.dev).wait_stream(self.streams[k])       # (x was produced there)
-            self.lanes[0].log_slots, keep = None, self.lanes[0].log_slots
-            try:
-                self.lanes[0].add_eager(x, y)
-            finally:
-                self.lanes[0].log_slots = keep
-            for s in self.streams:
-                s.wait_stream(torch.cuda.current_stream(self.dev))
+                        at = self.count - self.logged_from
+                        self.log_all[at:at + G].copy_(self.log_cur[k], non_blocking=True)
+                    self.count += G
+            # ---- what is left: one minibatch per replay, then the off-shape ones eagerly
+            while True:
+                k = turn % n_lanes
+                self._room(1)
+                single = self.singles[k]
+                with torch.cuda.stream(self.streams[k]):
+                    target["dst"] = lambda rows: single.slot(0) if rows == single.rows else None
+                    try:
+                        x, y = next(it)
+                    except StopIteration:
+                        break
+                    finally:
+                        target["dst"] = None
+                    if self.matches(x, y):
+                        turn += 1
+                        single.add(x, y)
+                        if self.n_bn:
+                            self.log_all[self.count - self.logged_from].copy_(self.log_cur1[k], non_blocking=True)
+                        self.count += 1
+                        continue
+                # an off-shape minibatch: in order, on the main stream, with the ordinary running-statistics update
+                self._join_and_replay()
+                x, y = x.to(self.dev), y.to(self.dev)
+                torch.cuda.current_stream(self.dev).wait_stream(self.streams[k])       # (x was produced there)
+                self.singles[0].log_slots, keep = None, self.singles[0].log_slots
+                try:
+                    self.singles[0].add_eager(x, y)
+                finally:
+                    self.singles[0].log_slots = keep
+                for s in self.streams:
+                    s.wait_stream(torch.cuda.current_stream(self.dev))
         self._join_and_replay()
 
     def _join_and_replay(self):
@@ -471,7 +560,7 @@ class ConcurrentAccumulate:
         main = torch.cuda.current_stream(self.dev)
         for s in self.streams:
             main.wait_stream(s)
-        for lane in self.lanes[1:]:
-            torch._foreach_add_(self.lanes[0].grads, lane.grads)
-            self.lanes[0].loss += lane.loss
-        self.lanes[0].finish()
+        for lane in self.singles[1:]:
+            torch._foreach_add_(self.singles[0].grads, lane.grads)
+            self.singles[0].loss += lane.loss
+        self.singles[0].finish()

@@ -14,6 +14,7 @@ What differs, by design (DESIGN.md "Runner"):
   epoch, drawn with exactly the RNG calls ``RandomSampler`` would make, instead of
   collating 128 single-example tensors per batch.
 """
+import contextlib
 import math
 
 import torch
@@ -77,6 +78,38 @@ class _BatchSource:
     def __len__(self):
         return len(self.dl)
 
+    # ---- minibatches produced straight into a consumer's buffers -------------------------------------------------
+    # ``with src.filling(provider):`` -- while the block iterates this source, every minibatch of ``rows`` rows is
+    # written into the (x_dst, y_dst) pair that ``provider(rows)`` returns (contiguous tensors of the batch's shape and
+    # dtype, e.g. slices of a captured graph's static inputs) and those are what the iteration yields; None from the
+    # provider (or no provider) = freshly allocated tensors as always.  Same minibatches, same RNG consumption.
+    _provider = None
+
+    @contextlib.contextmanager
+    def filling(self, provider):
+        old, self._provider = self._provider, provider
+        try:
+            yield self
+        finally:
+            self._provider = old
+
+    def n_full_batches(self):
+        "how many of this source's minibatches have the full batch size (None: unknown)"
+        if not self.fast:
+            return None
+        return len(self.dl.dataset) // self.dl.batch_size
+
+    def example(self):
+        "a full-size (x, y) minibatch of this source's shapes and dtypes without iterating it (None: unknown)"
+        if not self.fast or len(self.dl.dataset) < self.dl.batch_size:
+            return None
+        bs = self.dl.batch_size
+        return self.x[:bs], self.y[:bs]
+
+    def _dst(self, rows):
+        d = self._provider(rows) if self._provider is not None else None
+        return (None, None) if d is None else d
+
     def _permutation(self):
         """(permutation, generator) exactly as torch/utils/data/sampler.py RandomSampler.__iter__
         draws them; ``_exhausted`` below replays what it does when the iteration runs out."""
@@ -127,7 +160,9 @@ class _BatchSource:
             order = order.to(self.device)
             for i in range(0, stop, bs):
                 idx = order[i:i + bs]
-                yield self.augment.gather(self.x, idx, draw), self.y.index_select(0, idx)
+                xd, yd = self._dst(idx.numel())
+                yield (self.augment.gather(self.x, idx, draw, out=xd),
+                       self.y.index_select(0, idx) if yd is None else torch.index_select(self.y, 0, idx, out=yd))
             self._exhausted(gen)
             return
         if by_index:
@@ -140,11 +175,18 @@ class _BatchSource:
         if perm is not None:
             perm = perm.to(self.device)
         for i in range(0, stop, bs):
+            xd, yd = self._dst(min(bs, n - i))
             if perm is None:
-                yield self.x[i:i + bs], self.y[i:i + bs]
+                if xd is None:
+                    yield self.x[i:i + bs], self.y[i:i + bs]
+                else:
+                    yield xd.copy_(self.x[i:i + bs]), yd.copy_(self.y[i:i + bs])
             else:
                 idx = perm[i:i + bs]
-                yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+                if xd is None:
+                    yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+                else:
+                    yield torch.index_select(self.x, 0, idx, out=xd), torch.index_select(self.y, 0, idx, out=yd)
         self._exhausted(gen)
 
 

@@ -166,6 +166,7 @@ class _PoolLinear(torch.autograd.Function):
                 h.data_ptr(), weight.data_ptr(), p(bias), y.data_ptr(), pooled.data_ptr(), logits.data_ptr(), d.data_ptr(),
                 loss_rows.data_ptr(), dh.data_ptr(), p(sw), p(sb), p(src_y), h.data_ptr() if src_y is not None else 0,
                 p(src_saved[0]) if src_y is not None else 0, p(src_saved[1]) if src_y is not None else 0, p(partial),
+                _conv._group_imgs(n) if src_y is not None else 0,
                 p(counters), 0 if counters is None else counters.numel(), n, c, plane, k, gscale, _conv._stream())
             if err:
                 _hip.check(err, "sgmcmc_pool_linear_loss")
@@ -210,7 +211,8 @@ class _PoolLinear(torch.autograd.Function):
             err = _hip.lib().sgmcmc_pool_linear_bwd_sums(
                 dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
                 0 if sw is None else sw.data_ptr(), 0 if sb is None else sb.data_ptr(), src_y.data_ptr(), h.data_ptr(),
-                src_saved[0].data_ptr(), src_saved[1].data_ptr(), partial.data_ptr(), n, c, hh * ww, k, _conv._stream())
+                src_saved[0].data_ptr(), src_saved[1].data_ptr(), partial.data_ptr(), _conv._group_imgs(n), n, c, hh * ww,
+                k, _conv._stream())
             _bnlink.tag_gradient(dh, partial, n)
         else:
             err = _hip.lib().sgmcmc_pool_linear_bwd(dlogits.data_ptr(), pooled.data_ptr(), weight.data_ptr(), dh.data_ptr(),
@@ -372,6 +374,14 @@ def cross_entropy_backward(logits, y, reduction="mean", divide_by=None, want_los
             if not want_loss:
                 return None
             scale, _ = _grad_scale(logits.shape[0], reduction, divide_by)
+            from . import bn as _bn
+            G = _bn.groups()
+            if G > 1 and reduction == "sum" and logits.shape[0] % G == 0:
+                # several minibatches in one launch (bn.grouped): every minibatch's rows are summed as a pass over that
+                # minibatch alone sums them, the minibatches' sums added in double -- what the caller's accumulator does
+                loss = loss_rows.view(G, -1).sum(dim=1).mul_(scale)
+                loss = loss if divide_by is None else loss / divide_by
+                return loss.double().sum()
             loss = loss_rows.sum() * scale
             return loss if divide_by is None else loss / divide_by
     if not (xent_supported(logits, y) and logits.requires_grad):

@@ -113,15 +113,23 @@ class Potential:
         loss = torch.zeros((), dtype=torch.float64, device=self.opt.engine.device)
         if acc is not None:
             acc.begin()
-        batches = iter(batches)      # (never peeked at beyond what is consumed: iterating the loader draws from its RNG)
         if may_graph and acc is None:
-            first = next(batches, None)
+            # the capture needs a minibatch's shapes: from the source itself when it can tell (it then stays the object
+            # that ``ConcurrentAccumulate.run`` asks for in-place filling and the number of full-size minibatches),
+            # else from the first minibatch (never peeked at beyond what is consumed: iterating the loader draws from its RNG)
+            first = batches.example() if hasattr(batches, "example") else None
             if first is not None:
                 acc = self._exact_acc = self._make_exact_accumulator(*first)
                 acc.begin()
-                batches = itertools.chain([first], batches)
+            else:
+                batches = iter(batches)
+                first = next(batches, None)
+                if first is not None:
+                    acc = self._exact_acc = self._make_exact_accumulator(*first)
+                    acc.begin()
+                    batches = itertools.chain([first], batches)
         if acc is not None and hasattr(acc, "run"):
-            acc.run(batches)         # minibatches on several streams at once (graphed.ConcurrentAccumulate)
+            acc.run(batches)         # minibatches on several streams at once, several per launch (graphed.ConcurrentAccumulate)
             batches = ()
         for x, y in batches:
             if acc is not None:

@@ -38,7 +38,8 @@ ENABLED = os.environ.get("SGMCMC_BLOCK", "1") != "0"
 # 8 MB operand tensors staged by BOTH the data- and the weight-gradient workgroups cost 4 us more than the extra
 # launch saves, so that shape keeps the two-launch BatchNorm backward (and only fuses the shortcut's add).
 FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") == "" else \
-    {tuple(int(v) for v in item.split("x")) for item in os.environ["SGMCMC_BLOCK_FUSED"].split(",") if item}
+    {tuple(int(v) for v in item.split("x")) for item in os.environ["SGMCMC_BLOCK_FUSED"].split(",")
+     if item and item != "none"}
 # The route that replaced it (default): the BatchNorm backward's SUMS come out of the epilogue of the
 # convolution-gradient launch that produces the BatchNorm's incoming gradient (``sgmcmc_conv3x3_bwd_ex``), so a
 # BatchNorm backward is the dx launch alone and a block's backward is four launches whatever the shape:
@@ -46,6 +47,9 @@ FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") =
 #     dx(bn2) -> conv2 gradients [+ sums(bn1)] -> dx(bn1) -> conv1 gradients [+ dout*[out>0]] [+ sums(previous bn2)]
 # SGMCMC_BLOCK_EPILOGUE_SUMS=0 restores the routes above.
 EPILOGUE_SUMS = os.environ.get("SGMCMC_BLOCK_EPILOGUE_SUMS", "1") != "0"
+if not EPILOGUE_SUMS and FUSED_BN_BWD and not _hip.ALTERNATIVES:
+    raise RuntimeError("SGMCMC_BLOCK_EPILOGUE_SUMS=0 with fused shapes selects sgmcmc_conv3x3_bn_bwd, a measured "
+                       "alternative: build and load the library with SGMCMC_ALTERNATIVES=1 (or set SGMCMC_BLOCK_FUSED=none)")
 
 
 def supported(x, conv1, bn1, conv2, bn2):
@@ -73,11 +77,11 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
-    "y = conv3x3(x, w); out = relu(bn(y) [+ residual]) -> y, out, saved (mean, invstd)"
+def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s, G=1):
+    "y = conv3x3(x, w); out = relu(bn(y) [+ residual]) -> y, out, saved (mean, invstd; [2, G * C])"
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     y, out = torch.empty_like(x), torch.empty_like(x)
-    saved = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    saved = torch.empty((2, G * c), dtype=torch.float32, device=x.device)
     if _conv.PERSISTENT:
         slices = lib.sgmcmc_conv3x3_frag_stat_slices(n, c, hw)
         stats = torch.empty((c, slices, 2), dtype=torch.float64, device=x.device)
@@ -89,7 +93,7 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
         err = lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s)
     if err:
         _hip.check(err, "sgmcmc_conv3x3")
-    err = _bn.train_fwd(lib, y, residual, g, b, rm, rv, mom, eps, 1, n, c, hw * hw, out, saved, None, stats, slices, s)
+    err = _bn.train_fwd(lib, y, residual, g, b, rm, rv, mom, eps, 1, n, c, hw * hw, out, saved, None, stats, slices, s, G)
     if err:
         _hip.check(err, "sgmcmc_bn_train_fwd")
     return y, out, saved
@@ -103,6 +107,9 @@ def _conv_bn_fwd(lib, x, w, g, b, rm, rv, mom, eps, residual, s):
 # convolutions get slower by what the apply launch cost (csrc/conv_hip.inc, BnIn).  SGMCMC_FOLD_BN=1 enables it (its
 # statistics, exact integer totals, differ from the per-slice pairs' combination in rounding; tested at both settings).
 FOLD_BN = os.environ.get("SGMCMC_FOLD_BN", "0") == "1"
+if FOLD_BN and not _hip.ALTERNATIVES:
+    raise RuntimeError("SGMCMC_FOLD_BN=1 selects a measured alternative: build and load the library with "
+                       "SGMCMC_ALTERNATIVES=1")
 
 
 def _conv_bn_conv_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, s):
@@ -146,11 +153,11 @@ def _conv_bn_bwd_two_launch(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_ou
     """the same gradients with the BatchNorm backward as its own two launches (sums, dx) before conv3x3_bwd;
     e_dout / e_out: dx += e_dout * [e_out > 0] in the data gradient's epilogue (what the shortcut carries)"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
-    scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=x.device)
+    scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw, 1), dtype=torch.float64, device=x.device)
     dy = torch.empty_like(x)
     err = lib.sgmcmc_bn_train_bwd(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
-                                  saved[1].data_ptr(), 1, n, c, hw * hw, dy.data_ptr(), 0, dgb[0].data_ptr(),
-                                  dgb[1].data_ptr(), scratch.data_ptr(), s)
+                                  saved[1].data_ptr(), 1, n, c, hw * hw, dy.data_ptr(), 0, dgb.data_ptr(),
+                                  scratch.data_ptr(), 1, s)
     if err:
         _hip.check(err, "sgmcmc_bn_train_bwd")
     part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
@@ -171,10 +178,10 @@ def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
     """gradients of (x, w) through out = relu(bn(conv3x3(x, w)) [+ r]) given dout, BatchNorm backward inside the
     convolution-gradient launch; dgb [2][C] <- dgamma, dbeta; e_dout / e_out: dx += e_dout * [e_out > 0]"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
-    sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=x.device)
+    sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw, 1), dtype=torch.float64, device=x.device)
     n_sums = ctypes.c_int(0)
     err = lib.sgmcmc_bn_bwd_sums(dout.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
-                                 saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s)
+                                 saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, 1, s)
     if err:
         _hip.check(err, "sgmcmc_bn_bwd_sums")
     part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
@@ -191,31 +198,31 @@ def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
     return dx, _reduce_or_defer(lib, w, part, slabs.value, s)
 
 
-def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s):
-    "dy of out = relu(bn(y) [+ r]) given dout and the channel sums' partials; dgb [2][C] <- dgamma, dbeta"
+def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s, G=1):
+    "dy of out = relu(bn(y) [+ r]) given dout and the channel sums' partials; dgb [G][2][C] <- the groups' dgamma, dbeta"
     n, c, hw = y.shape[0], y.shape[1], y.shape[2]
     dy = torch.empty_like(y)
     err = lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
                                saved[1].data_ptr(), 1, n, c, hw * hw, partial.data_ptr(), n_partials, dy.data_ptr(), 0,
-                               dgb[0].data_ptr(), dgb[1].data_ptr(), None, s)
+                               dgb.data_ptr(), None, G, s)
     if err:
         _hip.check(err, "sgmcmc_bn_bwd_dx")
     return dy
 
 
-def _bn_sums(lib, dout, out, y, saved, s):
+def _bn_sums(lib, dout, out, y, saved, s, G=1):
     "the sums launch on its own -> (partial, n_partials)"
     n, c, hw = y.shape[0], y.shape[1], y.shape[2]
-    sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=y.device)
+    sums = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw, G), dtype=torch.float64, device=y.device)
     n_sums = ctypes.c_int(0)
     err = lib.sgmcmc_bn_bwd_sums(dout.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
-                                 saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s)
+                                 saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, G, s)
     if err:
         _hip.check(err, "sgmcmc_bn_bwd_sums")
     return sums, n_sums.value
 
 
-def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None):
+def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
     """both gradients of y = conv3x3(x, w) given dy; ``add`` = (e_dout, e_out): dx += e_dout * [e_out > 0];
     ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward whose incoming gradient
     dx is -> (dx, dw, partial or None, n_partials)"""
@@ -236,6 +243,7 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None):
         partial = torch.empty((c, n_partials, 2), dtype=torch.float64, device=x.device)
         E.s_y, E.s_out, E.s_mean, E.s_invstd = y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(), saved_bn[1].data_ptr()
         E.s_partial = partial.data_ptr()
+        E.group_imgs = n // G if G > 1 else 0
     slabs = ctypes.c_int(0)
     if _conv.SIDE_STREAM and _conv._may_defer(w):
         # the weight-gradient slabs leave the critical path: side stream, joined before the pass's slab reduction
@@ -255,6 +263,11 @@ class _Block(torch.autograd.Function):
         _conv._note_use(w1, w2)
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         s = _stream()
+        G = ctx.groups = _bn._groups_of(x)
+        if G > 1:
+            if FOLD_BN or _conv.PERSISTENT or not EPILOGUE_SUMS or _conv.SIDE_STREAM:
+                raise RuntimeError("bn.grouped(G > 1) runs on the default kernels only (no measured alternative)")
+            _conv._note_use(g1, b1, g2, b2)
         if FOLD_BN and not _conv.PERSISTENT:
             y1, h, saved1, y2, stats2, slices = _conv_bn_conv_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, s)
             n, c, hw = x.shape[0], x.shape[1], x.shape[2]
@@ -265,9 +278,9 @@ class _Block(torch.autograd.Function):
             if err:
                 _hip.check(err, "sgmcmc_bn_train_fwd")
         else:
-            y1, h, saved1 = _conv_bn_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, None, s)
-            y2, out, saved2 = _conv_bn_fwd(lib, h, w2, g2, b2, rm2, rv2, mom2, eps2, x, s)
-        ctx.save_for_backward(x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved)
+            y1, h, saved1 = _conv_bn_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, None, s, G)
+            y2, out, saved2 = _conv_bn_fwd(lib, h, w2, g2, b2, rm2, rv2, mom2, eps2, x, s, G)
+        ctx.save_for_backward(x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved, b1, b2)
         ctx.mark_non_differentiable(y2, saved2)
         ctx.set_materialize_grads(False)
         return out, y2, saved2        # (y2, saved2: where `out` came from, for the next operator -- bnlink)
@@ -276,32 +289,35 @@ class _Block(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout, *_):
         lib = _hip.lib()
-        x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved = ctx.saved_tensors
+        x, y1, h, y2, out, w1, w2, g1, g2, saved1, saved2, src_y, src_saved, b1, b2 = ctx.saved_tensors
         if dout is None:
             return (None,) * 17
         up = _bnlink.sums_of(dout) if EPILOGUE_SUMS else None
         dout = dout.contiguous()
         s = _stream()
-        dgb = torch.empty((2, 2, x.shape[1]), dtype=torch.float32, device=x.device)
+        G = ctx.groups
+        dgb = torch.empty((2, G, 2, x.shape[1]), dtype=torch.float32, device=x.device)     # [layer][group][gamma, beta][C]
         if EPILOGUE_SUMS:
             # bn2's sums: left by the launch that produced dout (the next block's conv1 gradient), else a launch here
-            sums2, n2 = up if up is not None else _bn_sums(lib, dout, out, y2, saved2, s)
-            dy2 = _bn_dx(lib, dout, out, y2, saved2, g2, dgb[1], sums2, n2, s)
-            dh, dw2, sums1, n1 = _conv_bwd_ex(lib, h, w2, dy2, s, sums_for=(y1, h, saved1))
-            dy1 = _bn_dx(lib, dh, h, y1, saved1, g1, dgb[0], sums1, n1, s)
+            sums2, n2 = up if up is not None else _bn_sums(lib, dout, out, y2, saved2, s, G)
+            dy2 = _bn_dx(lib, dout, out, y2, saved2, g2, dgb[1], sums2, n2, s, G)
+            dh, dw2, sums1, n1 = _conv_bwd_ex(lib, h, w2, dy2, s, sums_for=(y1, h, saved1), G=G)
+            dy1 = _bn_dx(lib, dh, h, y1, saved1, g1, dgb[0], sums1, n1, s, G)
             # ... and this block's input came out of a BatchNorm + ReLU too: its sums ride in conv1's gradient launch
             dx, dw1, sums0, n0 = _conv_bwd_ex(lib, x, w1, dy1, s, add=(dout, out),
-                                              sums_for=None if src_y is None else (src_y, x, src_saved))
+                                              sums_for=None if src_y is None else (src_y, x, src_saved), G=G)
             if sums0 is not None:
                 _bnlink.tag_gradient(dx, sums0, n0)
         elif (x.shape[1], x.shape[2]) in FUSED_BN_BWD:
-            dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
+            dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1, 0], None, None, s)
             # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue
-            dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
+            dx, dw1 = _conv_bn_bwd(lib, x, w1, y1, h, dh, saved1, g1, dgb[0, 0], dout, out, s)
         else:
             dh, dw2 = _conv_bn_bwd_two_launch(lib, h, w2, y2, out, dout, saved2, g2, dgb[1], None, None, s)
             dx, dw1 = _conv_bn_bwd_two_launch(lib, x, w1, y1, h, dh, saved1, g1, dgb[0], dout, out, s)
-        return (dx, dw1, dgb[0, 0], dgb[0, 1], dw2, dgb[1, 0], dgb[1, 1]) + (None,) * 10
+        dg1, db1 = _bn.sum_groups(dgb[0], g1, b1)
+        dg2, db2 = _bn.sum_groups(dgb[1], g2, b2)
+        return (dx, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 10
 
 
 def residual_block(x, conv1, bn1, conv2, bn2):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGMCMC_ABI_VERSION 5
+#define SGMCMC_ABI_VERSION 6
 #define SGMCMC_CHUNK 4096 /* default elements per arena chunk = 256 threads x 4 items x 4 elements */
 #define SGMCMC_CHUNK_SMALL 1024 /* small models: one item per thread, 4x more workgroups */
 #define SGMCMC_NSUMS 6
@@ -375,29 +375,6 @@ int sgmcmc_conv3x3_stat_slices(int n_img, int channels, int hw);
 int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int channels, int hw,
                    int transpose_w, double* stats, void* stream);
 
-/* A residual block's first BatchNorm + ReLU folded into its second convolution (models/google_resnet.py:34-43):
- *   sgmcmc_conv3x3_fx    y = conv3x3(x, w) and the batch statistics of y ADDED to `fx` -- per-XCD integer slots,
- *                        int64 [8][5][channels][16] (sgmcmc_fx_slot_int64(channels) elements), ZEROED by the caller:
- *                        integer atomics commute, so the totals carry the same bits whatever ran where;
- *   sgmcmc_conv3x3_bnin  y = conv3x3(relu(BatchNorm(x)), w): training-mode BatchNorm on the statistics in bn->fx and
- *                        the ReLU applied while the operands are staged, bn->h <- relu(BatchNorm(x)) as a side output
- *                        (the backward needs it), saved / running statistics (or the log slot) written as
- *                        sgmcmc_bn_train_fwd[_log] does; `stats`: y's own statistics per slice as sgmcmc_conv3x3.
- * The BatchNorm's apply launch and its read of x disappear. */
-typedef struct {
-  const int64_t* fx;
-  const float *gamma, *beta;
-  float *save_mean, *save_invstd, *running_mean, *running_var;
-  double* stat_log;
-  double momentum, eps;
-  float* h;
-} sgmcmc_bn_in;
-int64_t sgmcmc_fx_slot_int64(int channels);
-int sgmcmc_conv3x3_fx(const float* x, const float* w, float* y, int n_img, int channels, int hw, int64_t* fx,
-                      void* stream);
-int sgmcmc_conv3x3_bnin(const float* x, const float* w, float* y, int n_img, int channels, int hw, double* stats,
-                        const sgmcmc_bn_in* bn, void* stream);
-
 /* Weight gradient of the same convolution: dw[co,ci,r,s] = sum_{n,p} dy[n,co,p] x[n,ci,p+(r-1,s-1)].
  * `scratch` holds sgmcmc_conv3x3_wrw_scratch_floats(...) floats of per-workgroup partial slabs that a
  * second launch sums in a fixed order (deterministic; no atomics).  -1 / hipErrorInvalidValue for
@@ -412,7 +389,6 @@ int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratc
  * slabs in `scratch` and the caller sums them later -- typically all weight gradients of a backward pass
  * in ONE launch of sgmcmc_wrw_reduce_many (same summation order: same bits). */
 #define SGMCMC_REDUCE_JOBS 32
-#define SGMCMC_FRAG_JOBS 24   /* convolutions per launch of sgmcmc_conv3x3_prepare_weights */
 typedef struct sgmcmc_reduce_job {
   const float* part; /* [n_slabs][numel] */
   float* out;        /* [numel] */
@@ -440,47 +416,14 @@ typedef struct {
   const float *e_dout, *e_out;
   const float *s_y, *s_out, *s_mean, *s_invstd;
   double* s_partial;
+  int32_t group_imgs; /* > 0: the launch carries groups of this many images (sgmcmc_bn_train_fwd, GROUPS) and s_mean /
+                       * s_invstd are [groups][channels]; 0: one batch */
+  int32_t reserved;
 } sgmcmc_conv_bwd_epilogue;
 int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float* dx,
                           const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
                           int hw, int* deferred_slabs, void* stream);
-/* One half of sgmcmc_conv3x3_bwd_ex on its own: which = 1 the data gradient (dx, with the epilogues of `epi`, which may
- * be NULL), which = 2 the weight-gradient slabs (always deferred: *deferred_slabs receives their number).  The halves are
- * independent given dy, so a caller can run the weight gradient on a second stream, off the critical path of the
- * backward pass; same workgroups, same bits as the merged launch. */
-int sgmcmc_conv3x3_bwd_part(const float* x, const float* w, const float* dy, float* dx,
-                            const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
-                            int which, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
-
-/* ---- the same three contractions, PERSISTENT kernels on prepared weight fragments (csrc/conv2_hip.inc; round 3) ----
- * Replaces the convolutions of models/google_resnet.py:11-43 inside the gradient evaluation of inference.py:215-223,
- * as sgmcmc_conv3x3 / sgmcmc_conv3x3_bwd_ex do, for the same three shapes.  Differences:
- *   - the weights are read as MFMA fragments that sgmcmc_conv3x3_prepare_weights leaves in caller-owned buffers of
- *     channels^2 * 9 floats each (forward order and transposed + flipped for the data gradient): ONE launch for all
- *     convolutions of a gradient evaluation (up to SGMCMC_FRAG_JOBS per launch; more are split over launches);
- *   - items of 4 image rows; workgroups are persistent over a stream of items, XCD-aware (an image's items, its
- *     channel tiles and both of its gradients are processed on XCD = image mod 8);
- *   - statistics / backward-sum partials: [channels][sgmcmc_conv3x3_frag_stat_slices(...)][2] doubles, slice =
- *     image * (hw / 4) + band -- equal parts, as sgmcmc_bn_train_fwd / sgmcmc_bn_bwd_dx expect;
- *   - weight-gradient slabs: `scratch` = [channels / 16][P][9][16][channels] floats, P = *deferred_slabs: one reduction
- *     job PER 16-output-channel tile t (part = scratch + t * P * 144 * channels, out = dw + t * 144 * channels,
- *     numel = 144 * channels, taps = 9).  With dw != NULL and deferred_slabs == NULL the reductions are launched here.
- * Results agree with the round-2 kernels up to fp32 summation order; runs are bitwise reproducible. */
-typedef struct sgmcmc_frag_job {
-  const float* w;  /* [channels][channels][3][3] */
-  float* fwd;      /* channels^2 * 9 floats, or NULL */
-  float* dgrad;    /* channels^2 * 9 floats, or NULL */
-  int32_t channels, reserved;
-} sgmcmc_frag_job;
-int sgmcmc_conv3x3_prepare_weights(const sgmcmc_frag_job* jobs, int n_jobs, void* stream);
-int sgmcmc_conv3x3_frag_stat_slices(int n_img, int channels, int hw);
-int64_t sgmcmc_conv3x3_frag_scratch_floats(int n_img, int channels, int hw);
-int sgmcmc_conv3x3_frag_fwd(const float* x, const float* frag_fwd, float* y, int n_img, int channels, int hw,
-                            double* stats, void* stream);
-int sgmcmc_conv3x3_frag_bwd(const float* x, const float* frag_dgrad, const float* dy, float* dx,
-                            const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
-                            int hw, int* deferred_slabs, void* stream);
 
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;
  * the 1x1 shortcut's operand is the 3x3's centre tap): models/google_resnet.py:77-90.
@@ -570,52 +513,78 @@ int sgmcmc_conv50_pool_bwd(const float* x, const float* wT, const float* dpooled
 /* Training-mode batch normalisation over (N, H*W) per channel of an NCHW fp32 tensor, fused with the
  * optional residual add and ReLU that follow it in the ResNet trunk (models/google_resnet.py:34-43,
  * 77-90; replaces nn.BatchNorm2d + `+ shortcut` + ReLU inside R1's autograd graph):
- *   y = relu?(gamma * (x - mean) * invstd + beta [+ residual]);  save_mean / save_invstd [channels] are
+ *   y = relu?(gamma * (x - mean) * invstd + beta [+ residual]);  save_mean / save_invstd are
  *   written for the backward; running_mean / running_var (both or neither) get nn.BatchNorm2d's momentum
  *   update with the unbiased batch variance.  `plane` = H*W must be a multiple of 4.
  * Backward: dz = dy * (y > 0) when relu;  dresidual (optional) = dz;  dbeta = sum dz;
  *   dgamma = sum dz * xhat;  dx = gamma * invstd * (dz - dbeta/M - xhat * dgamma/M).
- * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane) doubles of per-slice partial sums, combined in
+ * `scratch`: sgmcmc_bn_scratch_doubles(n, channels, plane, groups) doubles of per-slice partial sums, combined in
  * a fixed order (deterministic).  Forward: when `stats_in` ([channels][stats_slices][2] partial (sum, sum of squared
- * deviations from the partial's own mean) of x over EQUAL parts, e.g. from sgmcmc_conv3x3) is given, the statistics pass over x is skipped. */
+ * deviations from the partial's own mean) of x over EQUAL parts, e.g. from sgmcmc_conv3x3) is given, the statistics
+ * pass over x is skipped.
+ *
+ * GROUPS (round 4).  `groups` = G >= 1 independent minibatches of n / G images each, stored one after the other, in ONE
+ * launch: the exact full-data gradient (inference_reject.py:18-33) evaluates its minibatches several per launch chain,
+ * and training-mode statistics are per minibatch (models/google_resnet.py:14-27).  Every group is normalised with its
+ * own batch statistics and gives the bits of a launch on that group alone:
+ *   - `n`, `stats_slices`, `n_partials` count the WHOLE launch (multiples of G); a producer's image-major partials
+ *     ([channels][slices][2] from the convolutions' epilogues) are read as [channels][G][slices / G][2];
+ *   - save_mean / save_invstd: [G][channels];  dgb: [G][2][channels] = every group's (dgamma, dbeta) -- a caller whose
+ *     parameters are shared by the groups sums the G rows (sgmcmc_wrw_reduce_many: n_slabs = G, numel = 2 channels);
+ *   - stat_log: group g's row at stat_log + g * log_stride doubles;
+ *   - running statistics cannot be advanced in place when G > 1 (the groups' updates are ordered): pass NULL or use
+ *     the logging entry point; hipErrorInvalidValue otherwise.
+ * gamma / beta are shared by the groups. */
 /* Evaluation mode (model.eval(): the per-epoch posterior-predictive evaluation of inference.py:199-213): one pass with
  * the running statistics, y = relu?(gamma (x - running_mean) / sqrt(running_var + eps) + beta [+ residual]). */
 int sgmcmc_bn_eval_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                        const float* running_mean, const float* running_var, double eps, int relu, int n,
                        int channels, int plane, float* y, void* stream);
-int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane);
+int64_t sgmcmc_bn_scratch_doubles(int n, int channels, int plane, int groups);
 int sgmcmc_bn_train_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, double momentum, double eps, int relu,
                         int n, int channels, int plane, float* y, float* save_mean, float* save_invstd,
-                        double* scratch, const double* stats_in, int stats_slices, void* stream);
+                        double* scratch, const double* stats_in, int stats_slices, int groups, void* stream);
 /* The same forward with the running statistics left ALONE: the batch mean and unbiased variance of every channel go to
- * stat_log[2 c + {0,1}] (doubles) instead, and sgmcmc_bn_running_replay advances running_mean / running_var by a
- * sequence of such entries (log + j * entry_stride doubles, j = 0 .. n_entries - 1) in order -- the same bits as
- * n_entries forwards in that order.  For gradient passes whose minibatches are evaluated concurrently on several
- * streams (the exact full-data pass, inference_reject.py:18-33) while nn.BatchNorm2d's running statistics must still
- * advance batch by batch. */
+ * stat_log[2 c + {0,1}] (doubles; group g: + g * log_stride) instead, and sgmcmc_bn_running_replay advances
+ * running_mean / running_var by a sequence of such entries (log + j * entry_stride doubles, j = 0 .. n_entries - 1) in
+ * order -- the same bits as n_entries forwards in that order.  For gradient passes whose minibatches are evaluated
+ * concurrently -- on several streams and / or several per launch (the exact full-data pass, inference_reject.py:18-33)
+ * -- while nn.BatchNorm2d's running statistics must still advance batch by batch. */
 int sgmcmc_bn_train_fwd_log(const float* x, const float* residual, const float* gamma, const float* beta,
-                            double* stat_log, double eps, int relu, int n, int channels, int plane, float* y,
-                            float* save_mean, float* save_invstd, double* scratch, const double* stats_in,
-                            int stats_slices, void* stream);
+                            double* stat_log, int64_t log_stride, double eps, int relu, int n, int channels, int plane,
+                            float* y, float* save_mean, float* save_invstd, double* scratch, const double* stats_in,
+                            int stats_slices, int groups, void* stream);
 int sgmcmc_bn_running_replay(const double* log, int64_t entry_stride, int n_entries, double momentum,
                              float* running_mean, float* running_var, int channels, void* stream);
 int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const float* gamma,
                         const float* save_mean, const float* save_invstd, int relu, int n, int channels,
-                        int plane, float* dx, float* dresidual, float* dgamma, float* dbeta,
-                        double* scratch, void* stream);
+                        int plane, float* dx, float* dresidual, float* dgb, double* scratch, int groups, void* stream);
+/* The first launch of sgmcmc_bn_train_bwd (relu = 1) on its own: per-slice partial sums of dz = dout * [out > 0] and
+ * dz * xhat, sums [channels][*n_sums][2] doubles (sgmcmc_bn_scratch_doubles(...) of them; *n_sums counts all groups). */
+int sgmcmc_bn_bwd_sums(const float* dout, const float* out, const float* y, const float* save_mean,
+                       const float* save_invstd, double* sums, int* n_sums, int n, int channels, int plane,
+                       int groups, void* stream);
 /* The second launch of sgmcmc_bn_train_bwd alone, for partial sums that already exist: `partial` =
  * [channels][n_partials][2] doubles (sum dz, sum dz * xhat per slice) from sgmcmc_bn_bwd_sums or from the epilogue of
- * the convolution gradient that produced dy (sgmcmc_conv3x3_bwd_ex). */
-/* rs (may be NULL; needs relu and dresidual): the residual is itself the output of a BatchNorm WITHOUT ReLU (the
+ * the convolution gradient that produced dy (sgmcmc_conv3x3_bwd_ex).
+ * rs (may be NULL; needs relu and dresidual): the residual is itself the output of a BatchNorm WITHOUT ReLU (the
  * down-sampling block's shortcut, models/google_resnet.py:77-90) whose incoming gradient is dresidual; the launch
  * also leaves that BatchNorm's backward sums in rs->partial, [channels][sgmcmc_bn_scratch_doubles(...) / (2
- * channels)][2] doubles (the slices of this launch's own geometry). */
+ * channels)][2] doubles (the slices of this launch's own geometry); rs->mean / rs->invstd: [G][channels]. */
+typedef struct {
+  const float *y, *mean, *invstd; /* the residual BatchNorm's input and saved statistics */
+  double* partial;
+} sgmcmc_bn_residual_sums;
+int sgmcmc_bn_bwd_dx(const float* dy, const float* y, const float* x, const float* gamma, const float* save_mean,
+                     const float* save_invstd, int relu, int n, int channels, int plane, const double* partial,
+                     int n_partials, float* dx, float* dresidual, float* dgb, const sgmcmc_bn_residual_sums* rs,
+                     int groups, void* stream);
 /* out = relu(BN(x) + BN_s(r)): a down-sampling block's last BatchNorm (models/google_resnet.py:77-90) with the 1x1
  * shortcut's BatchNorm -- no ReLU, this sum its only consumer -- applied on the fly: the shortcut BatchNorm's own
  * launch and its output tensor disappear; the same bits as sgmcmc_bn_train_fwd twice.  Training mode; both layers'
  * batch statistics as equal-part partial pairs [channels][slices][2] (a convolution epilogue's); save_* / running_* /
- * stat_log per layer as for sgmcmc_bn_train_fwd[_log]. */
+ * stat_log (+ log_stride) per layer as for sgmcmc_bn_train_fwd[_log]. */
 typedef struct {
   const float* r;     /* the shortcut BatchNorm's input */
   const float* gamma;
@@ -625,20 +594,12 @@ typedef struct {
   double eps, momentum;
   float *save_mean, *save_invstd, *running_mean, *running_var;
   double* stat_log;
+  int64_t log_stride;
 } sgmcmc_bn_dual;
 int sgmcmc_bn_train_fwd_dual(const float* x, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, double momentum, double eps, int n, int channels, int plane, float* y,
                              float* save_mean, float* save_invstd, const double* stats_in, int stats_slices,
-                             double* stat_log, const sgmcmc_bn_dual* rs, void* stream);
-
-typedef struct {
-  const float *y, *mean, *invstd; /* the residual BatchNorm's input and saved statistics */
-  double* partial;
-} sgmcmc_bn_residual_sums;
-int sgmcmc_bn_bwd_dx(const float* dy, const float* y, const float* x, const float* gamma, const float* save_mean,
-                     const float* save_invstd, int relu, int n, int channels, int plane, const double* partial,
-                     int n_partials, float* dx, float* dresidual, float* dgamma, float* dbeta,
-                     const sgmcmc_bn_residual_sums* rs, void* stream);
+                             double* stat_log, int64_t log_stride, const sgmcmc_bn_dual* rs, int groups, void* stream);
 
 /* y = maxpool2x2(relu(x + bias_c)), NCHW fp32, h and w even: the Conv2d(+bias) -> ReLU -> MaxPool2d(2) tail
  * of models/conv_nets.py:44-56 in one pass (the convolution itself is then run without its bias).
@@ -671,42 +632,17 @@ int sgmcmc_pool_linear_bwd(const float* dlogits, const float* pooled, const floa
 int sgmcmc_pool_linear_loss(const float* h, const float* weight, const float* bias, const int64_t* y, float* pooled,
                             float* logits, float* dlogits, float* loss_rows, float* dh, float* slab_w, float* slab_b,
                             const float* bn_y, const float* bn_out, const float* bn_mean, const float* bn_invstd,
-                            double* partial, int64_t* counters, int n_counters, int n, int channels, int plane,
-                            int classes, float grad_scale, void* stream);
+                            double* partial, int group_rows, int64_t* counters, int n_counters, int n, int channels,
+                            int plane, int classes, float grad_scale, void* stream);
 /* ... when h is the output of a BatchNorm + ReLU (bn_y its input, bn_out = h, saved mean / invstd) on 8x8 maps
  * (plane == 64): the launch also leaves that BatchNorm's backward sums, partial[(c * n + image) * 2 + {0,1}] doubles
- * (n slices per channel) for sgmcmc_bn_bwd_dx -- the last BatchNorm of models/google_resnet.py:103-110's trunk. */
+ * (n slices per channel) for sgmcmc_bn_bwd_dx -- the last BatchNorm of models/google_resnet.py:103-110's trunk.
+ * group_rows > 0: that BatchNorm ran on groups of group_rows rows (sgmcmc_bn_train_fwd, GROUPS): bn_mean / bn_invstd are
+ * [n / group_rows][channels]; 0: one batch. */
 int sgmcmc_pool_linear_bwd_sums(const float* dlogits, const float* pooled, const float* weight, float* dh,
                                 float* slab_w, float* slab_b, const float* bn_y, const float* bn_out,
-                                const float* bn_mean, const float* bn_invstd, double* partial, int n, int channels,
-                                int plane, int classes, void* stream);
-
-/* ---- BatchNorm backward folded into the convolution's gradient launch (csrc/conv_fused_hip.inc) ----------
- * For a "conv3x3 -> BatchNorm(train) -> [+ shortcut] -> ReLU" pair of the ResNet trunk (google_resnet.py:34-43,
- * 77-90), given dout = the gradient w.r.t. the pair's (post-ReLU) output `out`, y = the convolution's output:
- *
- *   sgmcmc_bn_bwd_sums: per-slice partial sums of dz = dout*[out>0] and dz*xhat, [channels][*n_sums][2] doubles
- *     (sgmcmc_bn_scratch_doubles(...) doubles) -- the first launch of sgmcmc_bn_train_bwd on its own;
- *   sgmcmc_conv3x3_bn_bwd: BOTH gradients of the convolution with
- *       dy = gamma*invstd * (dz - sum dz / M - xhat * sum(dz*xhat) / M),  xhat = (y - mean)*invstd
- *     formed while the operands are staged (what sgmcmc_bn_train_bwd's second launch would have written), plus
- *     dgamma = sum dz*xhat, dbeta = sum dz.  With e_dout / e_out given, dx += e_dout*[e_out > 0]: the gradient
- *     that reaches the convolution's INPUT through a shortcut whose ReLU mask is e_out (replaces an add launch).
- *     dw is left as *n_slabs partial slabs in `scratch` (sgmcmc_conv3x3_wrw_scratch_floats) for
- *     sgmcmc_wrw_reduce_many, as sgmcmc_conv3x3_bwd does with deferred_slabs. */
-typedef struct {
-  const float *dout, *mask_out, *y, *mean, *invstd, *gamma;
-  const double* sums;
-  int32_t n_sums, reserved;
-  float *dgamma, *dbeta;
-  const float *e_dout, *e_out;
-} sgmcmc_conv_bn_bwd_args;
-int sgmcmc_bn_bwd_sums(const float* dout, const float* out, const float* y, const float* save_mean,
-                       const float* save_invstd, double* sums, int* n_sums, int n, int channels, int plane,
-                       void* stream);
-int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scratch,
-                          const sgmcmc_conv_bn_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
-                          void* stream);
+                                const float* bn_mean, const float* bn_invstd, double* partial, int group_rows, int n,
+                                int channels, int plane, int classes, void* stream);
 
 /* A narrow linear layer, y = x W^T + b with out_features <= 16 (the convolutional classifier's head,
  * Flatten -> Linear(2450, 10), models/conv_nets.py:57-70): one launch each way, fixed-order reductions.

@@ -1,0 +1,116 @@
+/* Measured alternatives of libsgmcmc_hip.so -- NOT part of the shipped C ABI.
+ *
+ * Everything declared here lost to the default kernels inside the captured googleresnet step (DESIGN.md section 3 has the
+ * numbers) and is compiled only into a library built with -DSGMCMC_ALTERNATIVES (SGMCMC_ALTERNATIVES=1 in the
+ * environment of bnn_priors_amd._hip.build(); the tests that cover these entry points run only against such a build):
+ *
+ *   - sgmcmc_conv3x3_fx / _bnin          a residual block's first BatchNorm + ReLU folded into the second convolution's
+ *                                        operand staging (statistics through per-XCD integer atomics): 83 -> 77 launches,
+ *                                        the same steps/s;
+ *   - sgmcmc_conv3x3_bwd_part            the weight-gradient half of a convolution backward on a side stream: every
+ *                                        fork + join edge of a replayed graph costs ~19 us, 1,137 -> 845 steps/s;
+ *   - sgmcmc_conv3x3_prepare_weights /   persistent, double-buffered trunk convolutions on prepared weight fragments:
+ *     _frag_fwd / _frag_bwd              1-13 % faster per launch alone, 1,154 -> 1,131 steps/s in the step;
+ *   - sgmcmc_conv3x3_bn_bwd              the BatchNorm backward formed inside the convolution-gradient launch: needs a
+ *                                        sums launch of its own, 1,059 vs 1,122 steps/s.
+ *
+ * Same conventions as sgmcmc_hip.h (device pointers, hipStream_t as void*, hipError_t returned as int). */
+#ifndef SGMCMC_HIP_ALTERNATIVES_H
+#define SGMCMC_HIP_ALTERNATIVES_H
+#include "sgmcmc_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGMCMC_FRAG_JOBS 24   /* convolutions per launch of sgmcmc_conv3x3_prepare_weights */
+
+/* A residual block's first BatchNorm + ReLU folded into its second convolution (models/google_resnet.py:34-43):
+ *   sgmcmc_conv3x3_fx    y = conv3x3(x, w) and the batch statistics of y ADDED to `fx` -- per-XCD integer slots,
+ *                        int64 [8][5][channels][16] (sgmcmc_fx_slot_int64(channels) elements), ZEROED by the caller:
+ *                        integer atomics commute, so the totals carry the same bits whatever ran where;
+ *   sgmcmc_conv3x3_bnin  y = conv3x3(relu(BatchNorm(x)), w): training-mode BatchNorm on the statistics in bn->fx and
+ *                        the ReLU applied while the operands are staged, bn->h <- relu(BatchNorm(x)) as a side output
+ *                        (the backward needs it), saved / running statistics (or the log slot) written as
+ *                        sgmcmc_bn_train_fwd[_log] does; `stats`: y's own statistics per slice as sgmcmc_conv3x3.
+ * The BatchNorm's apply launch and its read of x disappear. */
+typedef struct {
+  const int64_t* fx;
+  const float *gamma, *beta;
+  float *save_mean, *save_invstd, *running_mean, *running_var;
+  double* stat_log;
+  double momentum, eps;
+  float* h;
+} sgmcmc_bn_in;
+int64_t sgmcmc_fx_slot_int64(int channels);
+int sgmcmc_conv3x3_fx(const float* x, const float* w, float* y, int n_img, int channels, int hw, int64_t* fx,
+                      void* stream);
+int sgmcmc_conv3x3_bnin(const float* x, const float* w, float* y, int n_img, int channels, int hw, double* stats,
+                        const sgmcmc_bn_in* bn, void* stream);
+
+
+/* One half of sgmcmc_conv3x3_bwd_ex on its own: which = 1 the data gradient (dx, with the epilogues of `epi`, which may
+ * be NULL), which = 2 the weight-gradient slabs (always deferred: *deferred_slabs receives their number).  The halves are
+ * independent given dy, so a caller can run the weight gradient on a second stream, off the critical path of the
+ * backward pass; same workgroups, same bits as the merged launch. */
+int sgmcmc_conv3x3_bwd_part(const float* x, const float* w, const float* dy, float* dx,
+                            const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
+                            int which, int* deferred_slabs, void* stream);
+
+/* ---- the same three contractions, PERSISTENT kernels on prepared weight fragments (csrc/conv2_hip.inc; round 3) ----
+ * Replaces the convolutions of models/google_resnet.py:11-43 inside the gradient evaluation of inference.py:215-223,
+ * as sgmcmc_conv3x3 / sgmcmc_conv3x3_bwd_ex do, for the same three shapes.  Differences:
+ *   - the weights are read as MFMA fragments that sgmcmc_conv3x3_prepare_weights leaves in caller-owned buffers of
+ *     channels^2 * 9 floats each (forward order and transposed + flipped for the data gradient): ONE launch for all
+ *     convolutions of a gradient evaluation (up to SGMCMC_FRAG_JOBS per launch; more are split over launches);
+ *   - items of 4 image rows; workgroups are persistent over a stream of items, XCD-aware (an image's items, its
+ *     channel tiles and both of its gradients are processed on XCD = image mod 8);
+ *   - statistics / backward-sum partials: [channels][sgmcmc_conv3x3_frag_stat_slices(...)][2] doubles, slice =
+ *     image * (hw / 4) + band -- equal parts, as sgmcmc_bn_train_fwd / sgmcmc_bn_bwd_dx expect;
+ *   - weight-gradient slabs: `scratch` = [channels / 16][P][9][16][channels] floats, P = *deferred_slabs: one reduction
+ *     job PER 16-output-channel tile t (part = scratch + t * P * 144 * channels, out = dw + t * 144 * channels,
+ *     numel = 144 * channels, taps = 9).  With dw != NULL and deferred_slabs == NULL the reductions are launched here.
+ * Results agree with the round-2 kernels up to fp32 summation order; runs are bitwise reproducible. */
+typedef struct sgmcmc_frag_job {
+  const float* w;  /* [channels][channels][3][3] */
+  float* fwd;      /* channels^2 * 9 floats, or NULL */
+  float* dgrad;    /* channels^2 * 9 floats, or NULL */
+  int32_t channels, reserved;
+} sgmcmc_frag_job;
+int sgmcmc_conv3x3_prepare_weights(const sgmcmc_frag_job* jobs, int n_jobs, void* stream);
+int sgmcmc_conv3x3_frag_stat_slices(int n_img, int channels, int hw);
+int64_t sgmcmc_conv3x3_frag_scratch_floats(int n_img, int channels, int hw);
+int sgmcmc_conv3x3_frag_fwd(const float* x, const float* frag_fwd, float* y, int n_img, int channels, int hw,
+                            double* stats, void* stream);
+int sgmcmc_conv3x3_frag_bwd(const float* x, const float* frag_dgrad, const float* dy, float* dx,
+                            const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
+                            int hw, int* deferred_slabs, void* stream);
+
+
+/* ---- BatchNorm backward folded into the convolution's gradient launch (csrc/conv_fused_hip.inc) ----------
+ * For a "conv3x3 -> BatchNorm(train) -> [+ shortcut] -> ReLU" pair of the ResNet trunk (google_resnet.py:34-43,
+ * 77-90), given dout = the gradient w.r.t. the pair's (post-ReLU) output `out`, y = the convolution's output:
+ *
+ *   (sgmcmc_bn_bwd_sums of sgmcmc_hip.h supplies the per-slice partial sums it needs, as a launch of its own)
+ *   sgmcmc_conv3x3_bn_bwd: BOTH gradients of the convolution with
+ *       dy = gamma*invstd * (dz - sum dz / M - xhat * sum(dz*xhat) / M),  xhat = (y - mean)*invstd
+ *     formed while the operands are staged (what sgmcmc_bn_train_bwd's second launch would have written), plus
+ *     dgamma = sum dz*xhat, dbeta = sum dz.  With e_dout / e_out given, dx += e_dout*[e_out > 0]: the gradient
+ *     that reaches the convolution's INPUT through a shortcut whose ReLU mask is e_out (replaces an add launch).
+ *     dw is left as *n_slabs partial slabs in `scratch` (sgmcmc_conv3x3_wrw_scratch_floats) for
+ *     sgmcmc_wrw_reduce_many, as sgmcmc_conv3x3_bwd does with deferred_slabs. */
+typedef struct {
+  const float *dout, *mask_out, *y, *mean, *invstd, *gamma;
+  const double* sums;
+  int32_t n_sums, reserved;
+  float *dgamma, *dbeta;
+  const float *e_dout, *e_out;
+} sgmcmc_conv_bn_bwd_args;
+int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scratch,
+                          const sgmcmc_conv_bn_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
+                          void* stream);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGMCMC_HIP_ALTERNATIVES_H */

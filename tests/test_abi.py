@@ -1,0 +1,45 @@
+"""The drop-in boundary: include/sgmcmc_hip.h, the ctypes table and the built library agree on
+the C ABI -- every declared entry point is bound and exported, nothing undeclared is exported, and the measured
+alternatives (include/sgmcmc_hip_alternatives.h) are NOT part of the shipped library.  No compute calls: runs without
+a GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from bnn_priors_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DECL = re.compile(r"^(?:int|int64_t|const char\*|void)\s+(sgmcmc_\w+)\s*\(", re.M)
+
+
+def _declared(header):
+    with open(os.path.join(ROOT, "include", header)) as f:
+        return set(DECL.findall(f.read()))
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {line.split()[-1] for line in out.splitlines() if " T sgmcmc_" in line}
+
+
+def test_header_ctypes_table_and_library_agree():
+    declared = _declared("sgmcmc_hip.h")
+    alt = _declared("sgmcmc_hip_alternatives.h")
+    assert len(declared) > 80 and not (declared & alt)
+    table = set(_hip.EXPORTS) - (set(_hip.ALT_EXPORTS) if _hip.ALTERNATIVES else set())
+    assert table == declared, (sorted(table - declared), sorted(declared - table))
+    assert set(_hip.ALT_EXPORTS) == alt, (sorted(set(_hip.ALT_EXPORTS) - alt), sorted(alt - set(_hip.ALT_EXPORTS)))
+    default_lib = os.path.join(ROOT, "bnn_priors_amd", "_build", "libsgmcmc_hip.so")
+    if not os.path.exists(default_lib):
+        pytest.skip("library not built")
+    exported = _exported(default_lib)
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))   # ... and no alternative in it
+
+
+def test_library_loads_and_binds_every_entry_point():
+    lib = _hip.lib()                      # raises HipExtensionMissing when the extension is absent: there is no fallback
+    assert lib.sgmcmc_abi_version() == _hip.ABI_VERSION
+    for name in _hip.EXPORTS:
+        assert getattr(lib, name).argtypes is not None

@@ -246,3 +246,99 @@ def test_down_sampling_block_with_the_shortcut_batchnorm_applied_on_the_fly_has_
     assert torch.equal(logs[True][0], logs[False][0])
     for a, b in zip(logs[True][1], logs[False][1]):
         assert torch.equal(a, b) and a.abs().sum() > 0
+
+
+# ---- several minibatches per launch (bn.grouped; csrc/bn_hip.inc GROUPS) ---------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,nb,c,hw", [(4, 128, 16, 32), (3, 128, 32, 16), (2, 128, 64, 8), (4, 5, 16, 32), (3, 1, 64, 8)])
+@pytest.mark.parametrize("relu,residual", [(True, False), (True, True), (False, False)])
+def test_grouped_batchnorm_has_the_bits_of_the_groups_run_alone(G, nb, c, hw, relu, residual):
+    """G minibatches in one launch: output, input gradient, residual gradient and the logged statistics of every group
+    are BIT-IDENTICAL to a launch on that group alone; (dgamma, dbeta) are the groups' sums (fixed order)."""
+    g = torch.Generator().manual_seed(G * 1000 + c)
+    n = G * nb
+    x = (torch.randn(n, c, hw, hw, generator=g) * 1.7 + 0.4).cuda()
+    x[nb:] += 0.8                                            # the groups' statistics differ
+    res = torch.randn(n, c, hw, hw, generator=g).cuda() if residual else None
+    w, b = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    dy = torch.randn(n, c, hw, hw, generator=g).cuda()
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+
+    def run(xs, rs, dys, groups):
+        leaves = [t.clone().requires_grad_() for t in (xs, w, b)] + ([rs.clone().requires_grad_()] if residual else [])
+        slot = torch.zeros((groups, c, 2) if groups > 1 else (c, 2), dtype=torch.float64, device="cuda")
+        with bn.logging_running_stats({id(rm): slot}), bn.grouped(groups):
+            y = bn.bn_train(leaves[0], leaves[1], leaves[2], rm, rv, 0.1, 1e-5, leaves[3] if residual else None, relu)
+            y.backward(dys)
+        return y.detach(), [t.grad for t in leaves], slot.view(-1, c, 2)
+
+    y, grads, log = run(x, res, dy, G)
+    assert torch.equal(rm, torch.zeros_like(rm)) and torch.equal(rv, torch.ones_like(rv))      # logged, not advanced
+    dw, db = torch.zeros_like(w, dtype=torch.float64), torch.zeros_like(b, dtype=torch.float64)
+    for k in range(G):
+        sl = slice(k * nb, (k + 1) * nb)
+        y1, g1, log1 = run(x[sl], res[sl] if residual else None, dy[sl], 1)
+        assert torch.equal(y[sl], y1), k
+        assert torch.equal(grads[0][sl], g1[0]), k
+        if residual:
+            assert torch.equal(grads[3][sl], g1[3]), k
+        assert torch.equal(log[k], log1[0]), k
+        dw += g1[1].double()
+        db += g1[2].double()
+    torch.testing.assert_close(grads[1].double(), dw, rtol=1e-6, atol=1e-6 * max(1.0, dw.abs().max().item()))
+    torch.testing.assert_close(grads[2].double(), db, rtol=1e-6, atol=1e-6 * max(1.0, db.abs().max().item()))
+    with pytest.raises(bn.LogModeUnsupported):               # without the log the groups' updates would be unordered
+        with bn.grouped(G):
+            bn.bn_train(x, w, b, rm, rv, 0.1, 1e-5, None, relu)
+    if n > G:
+        with pytest.raises(ValueError):                      # G * nb - 1 rows are not G equal minibatches
+            with bn.grouped(G), bn.logging_running_stats({id(rm): torch.zeros((G, c, 2), dtype=torch.float64, device="cuda")}):
+                bn.bn_train(x[:n - 1], w, b, rm, rv, 0.1, 1e-5, None, relu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,nb", [(4, 128), (3, 32), (2, 5)])
+def test_grouped_gradient_evaluation_of_the_resnet_equals_the_minibatches_one_by_one(G, nb):
+    """the whole googleresnet under bn.grouped(G) -- fused residual blocks, down-sampling pairs with the dual BatchNorm,
+    the stem, the fused head + loss, every BatchNorm backward's sums from an upstream epilogue looked up per group --
+    against the G minibatches evaluated one by one: logits and logged statistics bit-identical, the summed gradient to
+    rounding (the groups' slabs are added in another order)."""
+    import runner_cases as RC
+    from bnn_priors_amd import conv, models, pool
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(G * nb, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (G * nb,), generator=g).cuda()
+    model = RC.make_net(models, x[:2].cpu(), torch.tensor([0, 9]), device="cuda:0", cfg=dict(model="googleresnet"))
+    model.train()
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    params = [p for p in model.parameters()]
+    N = 50000.0
+
+    def run(xs, ys, groups):
+        cmax = max(m.num_features for m in bns)
+        cur = torch.zeros((groups, len(bns), cmax, 2), dtype=torch.float64, device="cuda")
+        slots = {id(m.running_mean): (cur[:, i, :m.num_features] if groups > 1 else cur[0, i, :m.num_features])
+                 for i, m in enumerate(bns)}
+        for p in params:
+            p.grad = None
+        with bn.logging_running_stats(slots), bn.grouped(groups), conv.deferring(model):
+            with pool.head_loss(ys, "sum", N):
+                f = model.net(xs)
+            loss = pool.cross_entropy_backward(f, ys, reduction="sum", divide_by=N)
+        torch.cuda.synchronize()
+        return f.detach().clone(), loss.double().item(), [p.grad.clone() for p in params], cur.clone()
+
+    f, loss, grads, log = run(x, y, G)
+    acc = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+    loss1 = 0.0
+    for k in range(G):
+        sl = slice(k * nb, (k + 1) * nb)
+        fk, lk, gk, logk = run(x[sl], y[sl], 1)
+        assert torch.equal(f[sl], fk), k
+        assert torch.equal(log[k], logk[0]), k
+        loss1 += lk
+        for a, t in zip(acc, gk):
+            a += t.double()
+    assert abs(loss - loss1) <= 1e-12 * abs(loss1)
+    for (name, _), a, t in zip(model.named_parameters(), acc, grads):
+        torch.testing.assert_close(t.double(), a, rtol=0, atol=2e-6 * max(1e-30, a.abs().max().item()), msg=name)

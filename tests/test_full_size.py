@@ -88,7 +88,7 @@ def test_rejected_proposal_restores_the_saved_state_exactly_at_googleresnet_size
 
 @pytest.mark.parametrize("model_name,shape,log_capacity", [("googleresnet", (3, 32, 32), 512), ("googleresnet", (3, 32, 32), 3),
                                                           ("classificationconvnet", (784,), 512)])
-def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape, log_capacity, monkeypatch):
+def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(model_name, shape, log_capacity, monkeypatch):
     """graphed.ConcurrentAccumulate (minibatches of the exact full-data gradient on two streams, BatchNorm statistics
     logged and replayed in order) against the one-stream pass AT THE SAME PARAMETERS and on the same batches, incl. a
     ragged last one: loss and gradient to rounding (another summation order over the minibatches), running statistics
@@ -112,11 +112,13 @@ def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape
         cycle_seed=RC.CYCLE_SEED, use_graph=True, **RC.RUN_KW)
     runner.begin()
     pot = runner._potential()
-    batches = list(train)
+    source = runner._batches()          # (fills the lanes' static inputs in place and tells how many minibatches are full)
     buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
     results = []
-    for lanes in (1, 2):
+    # one stream, minibatch by minibatch | two streams | ... with 3 (2 groups + 1 left over) and 4 minibatches per launch
+    for lanes, group, batches in ((1, 1, list(train)), (2, 1, source), (2, 3, source), (2, 4, source)):
         monkeypatch.setattr(graphed, "EXACT_LANES", lanes)
+        monkeypatch.setattr(graphed, "EXACT_GROUP", group)
         pot._exact_acc = None
         with torch.no_grad():
             for k, v in model.state_dict().items():
@@ -129,13 +131,16 @@ def test_exact_pass_on_two_streams_matches_the_sequential_pass(model_name, shape
             outs.append((loss.item(), potential.item(), [p.grad.clone() for p in pot.opt.engine.params],
                          {k: v.clone() for k, v in model.state_dict().items() if k in buffers}))
         assert isinstance(pot._exact_acc, graphed.ConcurrentAccumulate if lanes == 2 else graphed.GraphedAccumulate)
+        if lanes == 2:
+            assert pot._exact_acc.group == group
         results.append(outs)
-    for (l1, u1, g1, b1), (l2, u2, g2, b2) in zip(*results):
-        assert abs(l1 - l2) <= 1e-9 * abs(l1) and abs(u1 - u2) <= 1e-9 * abs(u1)
-        for a, b in zip(g1, g2):
-            torch.testing.assert_close(a, b, rtol=0, atol=2e-6 * max(1e-30, b.abs().max().item()))
-        assert sorted(b1) == sorted(b2)
-        for k in b1:
-            assert torch.equal(b1[k], b2[k]), k
+    for other in results[1:]:
+        for (l1, u1, g1, b1), (l2, u2, g2, b2) in zip(results[0], other):
+            assert abs(l1 - l2) <= 1e-9 * abs(l1) and abs(u1 - u2) <= 1e-9 * abs(u1)
+            for a, b in zip(g1, g2):
+                torch.testing.assert_close(a, b, rtol=0, atol=2e-6 * max(1e-30, b.abs().max().item()))
+            assert sorted(b1) == sorted(b2)
+            for k in b1:
+                assert torch.equal(b1[k], b2[k]), k
     if buffers:      # the statistics did advance (8 minibatches per pass)
         assert any(not torch.equal(results[0][0][3][k], buffers[k]) for k in buffers)

@@ -7,10 +7,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from bnn_priors_amd import conv
+from bnn_priors_amd import _hip, conv
 
 pytestmark = pytest.mark.gpu
 SHAPES = sorted(conv.SHAPES)
+# the measured alternatives exist only in a library built and loaded with SGMCMC_ALTERNATIVES=1 (include/sgmcmc_hip_alternatives.h)
+ALT = pytest.mark.skipif(not _hip.ALTERNATIVES, reason="measured alternative: needs the SGMCMC_ALTERNATIVES=1 build")
 
 
 def _block(c, seed=0):
@@ -68,10 +70,10 @@ def _route(monkeypatch, route):
     monkeypatch.setattr(resblock, "FUSED_BN_BWD", set(SHAPES) if route == "fused" else set())
 
 
-ROUTES = ["epilogue_sums", "fused", "two_launch"]
+ROUTES = ["epilogue_sums", pytest.param("fused", marks=ALT), "two_launch"]
 
 
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("fold", [pytest.param(True, marks=ALT), False])
 @pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
@@ -101,7 +103,7 @@ def test_fused_block_matches_float64_reference(c, hw, n, route, fold, monkeypatc
         torch.testing.assert_close(grads[k].double(), ref_g[k], rtol=2e-3, atol=3e-4 * scale(ref_g[k])), k
 
 
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("fold", [pytest.param(True, marks=ALT), False])
 @pytest.mark.parametrize("route", ROUTES[:2])
 @pytest.mark.parametrize("c,hw", SHAPES)
 def test_fused_block_is_bitwise_reproducible_and_matches_the_layered_path(c, hw, route, fold, monkeypatch):
@@ -199,6 +201,7 @@ def test_batchnorm_backward_sums_ride_in_the_upstream_convolution_gradient(monke
     assert bnlink.sums_of(t) is None
 
 
+@ALT
 def test_weight_gradients_on_a_side_stream_have_the_same_bits(monkeypatch):
     """conv.SIDE_STREAM (off by default: measured slower inside a replayed graph): the weight-gradient half of every
     trunk convolution's backward on a second stream, joined before the pass's slab reduction -- same workgroups, so
@@ -226,6 +229,7 @@ def test_weight_gradients_on_a_side_stream_have_the_same_bits(monkeypatch):
         assert torch.equal(a, b)
 
 
+@ALT
 @pytest.mark.parametrize("c,hw", SHAPES)
 def test_folded_first_batchnorm_logs_its_statistics_and_sums_exactly(c, hw, monkeypatch):
     """the folded route in logging mode (the exact pass's lanes): the first BatchNorm's batch mean / unbiased variance

@@ -1,5 +1,6 @@
 """Dispatch-packet timing of the BatchNorm kernels at the trunk's three shapes: apply (statistics supplied by the
-convolution epilogue), backward sums, backward dx.  python tools/bn_micro.py [--iters 40]"""
+convolution epilogue), backward sums, backward dx.  python tools/bn_micro.py [--iters 40] [--groups G]
+(--groups G: G minibatches of --n images per launch, the exact pass's grouped mode; logging statistics)"""
 import argparse
 import ctypes
 import os
@@ -13,8 +14,10 @@ from bnn_priors_amd import _hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--n", type=int, default=128)
+ap.add_argument("--groups", type=int, default=1)
 a = ap.parse_args()
-lib, dev, n = _hip.lib(), torch.device("cuda", 0), a.n
+G = a.groups
+lib, dev, n = _hip.lib(), torch.device("cuda", 0), a.n * G
 s = torch.cuda.current_stream(dev).cuda_stream
 for c, hw in ((16, 32), (32, 16), (64, 8)):
     g = torch.Generator(device=dev).manual_seed(c)
@@ -28,36 +31,45 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, stats.data_ptr(), s), "conv")
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
-    saved = torch.empty((2, c), device=dev)
-    dgb = torch.empty((2, c), device=dev)
-    scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=dev)
+    saved = torch.empty((2, G * c), device=dev)
+    dgb = torch.empty((G, 2, c), device=dev)
+    log = torch.empty((G, c, 2), dtype=torch.float64, device=dev)
+    scratch = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw, G), dtype=torch.float64, device=dev)
 
     def fwd(r):
+        if G > 1:
+            return lib.sgmcmc_bn_train_fwd_log(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), log.data_ptr(), 2 * c,
+                                               1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(),
+                                               saved[1].data_ptr(), 0, stats.data_ptr(), slices, G, s)
         return lib.sgmcmc_bn_train_fwd(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
                                        1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 0,
-                                       stats.data_ptr(), slices, s)
-    stats8 = stats[:, :8].contiguous()          # (timing only) what a prologue over 8 partial pairs per channel costs
+                                       stats.data_ptr(), slices, 1, s)
+    stats8 = stats[:, :8 * G].contiguous()      # (timing only) what a prologue over 8 partial pairs per channel costs
     part = torch.randn((c, slices, 2), generator=g, device=dev, dtype=torch.float64)
-    part8 = part[:, :8].contiguous()
+    part8 = part[:, :8 * G].contiguous()
 
     def fwd8(r):
+        if G > 1:
+            return lib.sgmcmc_bn_train_fwd_log(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), log.data_ptr(), 2 * c,
+                                               1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(),
+                                               saved[1].data_ptr(), 0, stats8.data_ptr(), 8 * G, G, s)
         return lib.sgmcmc_bn_train_fwd(y.data_ptr(), r, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
                                        1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 0,
-                                       stats8.data_ptr(), 8, s)
+                                       stats8.data_ptr(), 8, 1, s)
 
     def dx(pt, k):
         return lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(),
                                     saved[1].data_ptr(), 1, n, c, hw * hw, pt.data_ptr(), k, dx_.data_ptr(), 0,
-                                    dgb[0].data_ptr(), dgb[1].data_ptr(), None, s)
+                                    dgb.data_ptr(), None, G, s)
     cases = {
         "apply, 8 partials per channel": lambda: fwd8(0),
-        f"bwd_dx, {slices} partials per channel": lambda: dx(part, slices),
-        "bwd_dx, 8 partials per channel": lambda: dx(part8, 8),
+        f"bwd_dx, {slices // G} partials per channel": lambda: dx(part, slices),
+        "bwd_dx, 8 partials per channel": lambda: dx(part8, 8 * G),
         "apply": lambda: fwd(0),
         "apply+res": lambda: fwd(res.data_ptr()),
         "bwd_sums (first launch of bwd)": lambda: lib.sgmcmc_bn_train_bwd(
             dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(), saved[1].data_ptr(), 1, n, c,
-            hw * hw, dx_.data_ptr(), 0, dgb[0].data_ptr(), dgb[1].data_ptr(), scratch.data_ptr(), s),
+            hw * hw, dx_.data_ptr(), 0, dgb.data_ptr(), scratch.data_ptr(), G, s),
     }
     for name, fn in cases.items():
         for _ in range(5):

@@ -26,12 +26,12 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
     stats = torch.empty((c, slices, 2), dtype=torch.float64, device=dev)
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), device=dev)
-    sums = torch.zeros(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw), dtype=torch.float64, device=dev)
+    sums = torch.zeros(lib.sgmcmc_bn_scratch_doubles(n, c, hw * hw, 1), dtype=torch.float64, device=dev)
     saved = torch.stack([torch.zeros(c, device=dev), torch.ones(c, device=dev)])
     gamma, dgb = torch.ones(c, device=dev), torch.empty((2, c), device=dev)
     slabs, n_sums = ctypes.c_int(0), ctypes.c_int(0)
     _hip.check(lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
-                                      saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s), "sums")
+                                      saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, 1, s), "sums")
     A = _hip.ConvBnBwdArgs(dout=dy.data_ptr(), mask_out=out.data_ptr(), y=y.data_ptr(), mean=saved[0].data_ptr(),
                            invstd=saved[1].data_ptr(), gamma=gamma.data_ptr(), sums=sums.data_ptr(),
                            n_sums=n_sums.value, reserved=0, dgamma=dgb[0].data_ptr(), dbeta=dgb[1].data_ptr(),
@@ -54,10 +54,11 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
                                                      scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s),
         "bwd+add+sums": lambda: lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E_as), 0,
                                                           scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s),
-        "bn_bwd": lambda: lib.sgmcmc_conv3x3_bn_bwd(x.data_ptr(), w.data_ptr(), dx.data_ptr(), scratch.data_ptr(),
-                                                    ctypes.byref(A), n, c, hw, ctypes.byref(slabs), s),
+        **({"bn_bwd": lambda: lib.sgmcmc_conv3x3_bn_bwd(x.data_ptr(), w.data_ptr(), dx.data_ptr(), scratch.data_ptr(),
+                                                       ctypes.byref(A), n, c, hw, ctypes.byref(slabs), s)}
+           if _hip.ALTERNATIVES else {}),       # (SGMCMC_ALTERNATIVES=1 builds only)
         "bn_bwd_sums": lambda: lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),
-                                                      saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, s),
+                                                      saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, hw * hw, 1, s),
     }
     for name, fn in cases.items():
         for _ in range(5):
