@@ -130,9 +130,35 @@ class PoolSource:
     def __len__(self):
         return self.n_batches
 
+    # (the three hooks of inference._BatchSource that the exact pass uses: in-place filling of a consumer's buffers,
+    # the number of full-size minibatches, a minibatch's shapes)
+    _provider = None
+
+    def filling(self, provider):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old, self._provider = self._provider, provider
+            try:
+                yield self
+            finally:
+                self._provider = old
+        return scope()
+
+    def n_full_batches(self):
+        return self.n_rows // 128
+
+    def example(self):
+        return self.x[:128], self.y[:128]
+
     def __iter__(self):
         for b in range(self.n_batches):
-            yield self.x[128 * b:128 * (b + 1)], self.y[128 * b:128 * (b + 1)]
+            x, y = self.x[128 * b:128 * (b + 1)], self.y[128 * b:128 * (b + 1)]
+            dst = self._provider(len(x)) if self._provider is not None else None
+            if dst is not None:
+                x, y = dst[0].copy_(x), dst[1].copy_(y)
+            yield x, y
 
     def index_batches(self):
         import numpy as np

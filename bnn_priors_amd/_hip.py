@@ -91,7 +91,7 @@ class ReduceJob(ctypes.Structure):
 class ConvBwdEpilogue(ctypes.Structure):
     "sgmcmc_conv_bwd_epilogue"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
-                + [("group_imgs", ctypes.c_int32), ("reserved", ctypes.c_int32)])
+                + [("group_imgs", ctypes.c_int32), ("wrw_mult", ctypes.c_int32)])
 
 
 class BnResidualSums(ctypes.Structure):
@@ -106,6 +106,12 @@ class BnDual(ctypes.Structure):
                    ("momentum", ctypes.c_double)]
                 + [(n, ctypes.c_void_p) for n in ("save_mean", "save_invstd", "running_mean", "running_var", "stat_log")]
                 + [("log_stride", ctypes.c_int64)])
+
+
+class BnReplayLayer(ctypes.Structure):
+    "sgmcmc_bn_replay_layer"
+    _fields_ = [("log", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("momentum", ctypes.c_double), ("channels", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class BnIn(ctypes.Structure):
@@ -227,6 +233,8 @@ EXPORTS = {
                                 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_bn_running_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_bn_running_replay_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                                     ctypes.c_void_p]),
     "sgmcmc_bn_train_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4
                             + [ctypes.c_int, ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3

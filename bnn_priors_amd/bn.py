@@ -175,6 +175,19 @@ def replay_running_stats(log, entry_stride, n_entries, momentum, running_mean, r
         _hip.check(err, "sgmcmc_bn_running_replay")
 
 
+def replay_running_stats_many(layers, log_all, n_entries, stream):
+    """every layer's running statistics advanced by the first ``n_entries`` rows of ``log_all`` ([capacity, n_layers,
+    cmax, 2] float64: row j, column i = layer i's batch mean / unbiased variance of logged minibatch j) -- one launch"""
+    n = len(layers)
+    arr = (_hip.BnReplayLayer * n)()
+    for i, (a, m) in enumerate(zip(arr, layers)):
+        a.log, a.running_mean, a.running_var = log_all[0, i].data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr()
+        a.momentum, a.channels = float(m.momentum), m.num_features
+    err = _hip.lib().sgmcmc_bn_running_replay_many(ctypes.cast(arr, ctypes.c_void_p), n, log_all.stride(0), n_entries, stream)
+    if err:
+        _hip.check(err, "sgmcmc_bn_running_replay_many")
+
+
 class _BNTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats_in,

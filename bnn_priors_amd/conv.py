@@ -302,6 +302,11 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
     return dx, dw, partial, n_part
 
 
+# launches that carry G minibatches (bn.grouped): every weight-gradient workgroup of the trunk's 3x3 convolutions walks G
+# times as many items, so a pass leaves the slabs of ONE minibatch (SGMCMC_WRW_GROUP_MULT=0: G times as many slabs)
+WRW_GROUP_MULT = os.environ.get("SGMCMC_WRW_GROUP_MULT", "1") != "0"
+
+
 def _group_imgs(n):
     "images per group for a launch that looks a BatchNorm's saved statistics up by image (bn.grouped); 0: one batch"
     from . import bn as _bn
@@ -347,6 +352,8 @@ def _both_grads(x, w, dy, defer, sums_for=None):
         E = _hip.ConvBwdEpilogue(s_y=y_bn.data_ptr(), s_out=out_bn.data_ptr(), s_mean=saved_bn[0].data_ptr(),
                                  s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr(),
                                  group_imgs=_group_imgs(n))
+        from . import bn as _bn
+        E.wrw_mult = WRW_GROUP_MULT and _bn.groups()
         err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
                                         dw.data_ptr(), scratch.data_ptr(), n, c, hw,
                                         ctypes.byref(slabs) if defer else None, _stream())

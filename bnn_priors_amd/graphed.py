@@ -397,7 +397,7 @@ class GraphedAccumulate:
 
 
 # ------------------------------------------------------------------ the exact pass on several streams
-EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "2"))
+EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "3"))      # streams (3 with grouped launches: 189 vs 200 ms per googleresnet pass at 2; at one minibatch per launch 2 was the optimum)
 EXACT_GROUP = int(os.environ.get("SGMCMC_EXACT_GROUP", "4"))      # minibatches per launch chain (1: one, as round 3)
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
@@ -545,10 +545,7 @@ class ConcurrentAccumulate:
             main.wait_stream(s)
         n = self.count - self.logged_from
         if n and self.n_bn:
-            stride = self.log_all.stride(0)
-            for i, m in enumerate(self.bn_layers):
-                _bn.replay_running_stats(self.log_all[0, i].data_ptr(), stride, n, m.momentum, m.running_mean,
-                                         m.running_var, main.cuda_stream)
+            _bn.replay_running_stats_many(self.bn_layers, self.log_all, n, main.cuda_stream)
             with torch.no_grad():
                 torch._foreach_add_([m.num_batches_tracked for m in self.bn_layers], n)
         self.logged_from = self.count

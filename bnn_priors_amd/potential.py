@@ -83,9 +83,10 @@ class Potential:
         convolutional nets on EXACT_LANES streams at once (graphed.ConcurrentAccumulate)"""
         from . import bn as _bn, graphed
         from .models import nets
-        if graphed.EXACT_LANES > 1 and any(isinstance(m, nets.Conv2d) for m in self.model.modules()):
+        if ((graphed.EXACT_LANES > 1 or graphed.EXACT_GROUP > 1)
+                and any(isinstance(m, nets.Conv2d) for m in self.model.modules())):
             try:
-                return graphed.ConcurrentAccumulate(self, self.opt, x, y, lanes=graphed.EXACT_LANES)
+                return graphed.ConcurrentAccumulate(self, self.opt, x, y, lanes=max(1, graphed.EXACT_LANES))
             except _bn.LogModeUnsupported:
                 pass
         return graphed.GraphedAccumulate(self, self.opt, x, y)

@@ -235,6 +235,7 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
     part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     E = _hip.ConvBwdEpilogue()
+    E.wrw_mult = _conv.WRW_GROUP_MULT and G       # (several minibatches: the slab count of one)
     if add is not None:
         E.e_dout, E.e_out = add[0].data_ptr(), add[1].data_ptr()
     partial, n_partials = None, lib.sgmcmc_conv3x3_stat_slices(n, c, hw)

@@ -418,7 +418,10 @@ typedef struct {
   double* s_partial;
   int32_t group_imgs; /* > 0: the launch carries groups of this many images (sgmcmc_bn_train_fwd, GROUPS) and s_mean /
                        * s_invstd are [groups][channels]; 0: one batch */
-  int32_t reserved;
+  int32_t wrw_mult;   /* sgmcmc_conv3x3_bwd_ex only; > 1: every weight-gradient workgroup sums over wrw_mult times as many
+                       * (image, band) items, i.e. *deferred_slabs shrinks by that factor -- for launches that carry
+                       * several minibatches (the slab count of ONE minibatch, each slab the sum over more images;
+                       * another summation grouping than wrw_mult = 1: equal to rounding); 0 / 1: the default */
 } sgmcmc_conv_bwd_epilogue;
 int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float* dx,
                           const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
@@ -557,6 +560,17 @@ int sgmcmc_bn_train_fwd_log(const float* x, const float* residual, const float* 
                             int stats_slices, int groups, void* stream);
 int sgmcmc_bn_running_replay(const double* log, int64_t entry_stride, int n_entries, double momentum,
                              float* running_mean, float* running_var, int channels, void* stream);
+/* ... for all BatchNorm layers of a network in ONE launch (any number: SGMCMC_BN_REPLAY_LAYERS per launch): layer i's
+ * entries are layers[i].log + j * entry_stride (the layers' columns of one log array). */
+#define SGMCMC_BN_REPLAY_LAYERS 32
+typedef struct sgmcmc_bn_replay_layer {
+  const double* log;
+  float *running_mean, *running_var;
+  double momentum;
+  int32_t channels, reserved;
+} sgmcmc_bn_replay_layer;
+int sgmcmc_bn_running_replay_many(const sgmcmc_bn_replay_layer* layers, int n_layers, int64_t entry_stride,
+                                  int n_entries, void* stream);
 int sgmcmc_bn_train_bwd(const float* dy, const float* y, const float* x, const float* gamma,
                         const float* save_mean, const float* save_invstd, int relu, int n, int channels,
                         int plane, float* dx, float* dresidual, float* dgb, double* scratch, int groups, void* stream);

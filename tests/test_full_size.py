@@ -115,8 +115,9 @@ def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(mod
     source = runner._batches()          # (fills the lanes' static inputs in place and tells how many minibatches are full)
     buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
     results = []
-    # one stream, minibatch by minibatch | two streams | ... with 3 (2 groups + 1 left over) and 4 minibatches per launch
-    for lanes, group, batches in ((1, 1, list(train)), (2, 1, source), (2, 3, source), (2, 4, source)):
+    # one stream, minibatch by minibatch | two streams | ... with 3 (2 groups + 1 left over) and 4 minibatches per launch |
+    # one stream with 4 per launch
+    for lanes, group, batches in ((1, 1, list(train)), (2, 1, source), (2, 3, source), (2, 4, source), (1, 4, source)):
         monkeypatch.setattr(graphed, "EXACT_LANES", lanes)
         monkeypatch.setattr(graphed, "EXACT_GROUP", group)
         pot._exact_acc = None
@@ -130,8 +131,8 @@ def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(mod
             torch.cuda.synchronize()
             outs.append((loss.item(), potential.item(), [p.grad.clone() for p in pot.opt.engine.params],
                          {k: v.clone() for k, v in model.state_dict().items() if k in buffers}))
-        assert isinstance(pot._exact_acc, graphed.ConcurrentAccumulate if lanes == 2 else graphed.GraphedAccumulate)
-        if lanes == 2:
+        assert isinstance(pot._exact_acc, graphed.ConcurrentAccumulate if (lanes, group) != (1, 1) else graphed.GraphedAccumulate)
+        if (lanes, group) != (1, 1):
             assert pot._exact_acc.group == group
         results.append(outs)
     for other in results[1:]:
