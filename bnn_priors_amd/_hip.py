@@ -14,8 +14,8 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SGMCMC_ALTERNATIVES=1: the library that ALSO carries the measured alternatives (include/sgmcmc_hip_alternatives.h:
-# persistent convolutions, folded BatchNorm, fused BatchNorm backward, side-stream weight gradients) -- a separate file,
-# so the shipped library never contains them; the switches that select them (conv.PERSISTENT, resblock.FOLD_BN, ...)
+# folded BatchNorm, fused BatchNorm backward, side-stream weight gradients) -- a separate file,
+# so the shipped library never contains them; the switches that select them (resblock.FOLD_BN, conv.SIDE_STREAM, ...)
 # refuse to turn on without it.
 ALTERNATIVES = os.environ.get("SGMCMC_ALTERNATIVES", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "_build", "libsgmcmc_hip_alt.so" if ALTERNATIVES else "libsgmcmc_hip.so")
@@ -306,6 +306,12 @@ EXPORTS = {
     "sgmcmc_debug_normals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_frag_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2),
+    "sgmcmc_conv3x3_frag_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
+                                + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
 }
 
 # include/sgmcmc_hip_alternatives.h (libsgmcmc_hip_alt.so only)
@@ -316,12 +322,6 @@ ALT_EXPORTS = {
                             + [ctypes.c_void_p, ctypes.POINTER(BnIn), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bwd_part": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
                                 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
-    "sgmcmc_conv3x3_prepare_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "sgmcmc_conv3x3_frag_stat_slices": (ctypes.c_int, [ctypes.c_int] * 3),
-    "sgmcmc_conv3x3_frag_scratch_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
-    "sgmcmc_conv3x3_frag_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2),
-    "sgmcmc_conv3x3_frag_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue)]
-                                + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
                               + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
 }

@@ -9,18 +9,17 @@ and 1x1 convolutions, the 3-channel stem, other dtypes, CPU tensors) stays on AT
 Reference: the convolutions of bnn_priors/models/google_resnet.py:34-43 inside the gradient
 evaluation of inference.py:215-223.
 """
+import collections
+import contextlib
 import ctypes
 import os
+import warnings
+import weakref
 
 import torch
 
 from . import _hip
 from . import bnlink as _bnlink
-
-import collections
-import contextlib
-import warnings
-import weakref
 
 # Layers of a GPU model that did NOT take one of this package's kernels (a shape off the tables, a switch set to 0)
 # are counted here per (operator, per-sample shape); SGMCMC_STRICT=1 turns such a library dispatch into an error --
@@ -47,15 +46,26 @@ def library_path(op, x):
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
 ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
 DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
-# the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc).  MEASURED ALTERNATIVE, off by default: in the
-# standalone lab they are 1-13 % faster per launch than the round-2 kernels (tools/conv_lab, profiles/r03_conv_lab*),
-# inside the captured step they are not (googleresnet 1,154 -> 1,131 steps/s: cold operands of the epilogues, the
-# fragment launch, twice the slab bytes at 64 channels, twice the statistics slices for the BatchNorm kernels) --
-# DESIGN.md section 3.  SGMCMC_CONV_PERSISTENT=1 selects them (same results up to fp32 summation order: tested).
+# the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc): double-buffered workgroups over a stream of
+# 4-row items.  WHERE THEY RUN: launches that carry several minibatches (``persistent()`` below: the grouped exact
+# full-data pass, graphed.py) -- 10-20 % faster per launch at 512 images (tools/conv_lab), the googleresnet pass 190 ->
+# 172 ms.  NOT the 128-image leapfrog step: there they are slower inside the captured graph (1,154 -> 1,131 steps/s:
+# cold operands of the epilogues, the fragment launch, twice the slab bytes at 64 channels, twice the statistics slices
+# for the BatchNorm kernels -- DESIGN.md section 3).  SGMCMC_CONV_PERSISTENT=1 selects them everywhere (same results up
+# to fp32 summation order: tested).
 PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "0") == "1"
-if PERSISTENT and not _hip.ALTERNATIVES:
-    raise RuntimeError("SGMCMC_CONV_PERSISTENT=1 selects a measured alternative: build and load the library with "
-                       "SGMCMC_ALTERNATIVES=1")
+
+
+@contextlib.contextmanager
+def persistent(on=True):
+    "scope in which the trunk's 3x3 convolutions (forward and both gradients) run on the persistent kernels"
+    global PERSISTENT
+    old, PERSISTENT = PERSISTENT, bool(on) or PERSISTENT
+    try:
+        yield
+    finally:
+        PERSISTENT = old
+
 
 # ---- prepared weight fragments (csrc/conv2_hip.inc) ------------------------------------------------------------
 # The persistent kernels read a convolution's weights in MFMA fragment order (forward, and transposed + flipped for
@@ -288,6 +298,7 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
         E.s_y, E.s_out, E.s_mean, E.s_invstd = (y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(),
                                                 saved_bn[1].data_ptr())
         E.s_partial = partial.data_ptr()
+        E.group_imgs = _group_imgs(n)
     slabs = ctypes.c_int(0)
     err = lib.sgmcmc_conv3x3_frag_bwd(x.data_ptr(), frags(w)[1].data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
                                       0 if defer else dw.data_ptr(), scratch.data_ptr(), n, c, hw,
@@ -311,8 +322,8 @@ def _group_imgs(n):
     "images per group for a launch that looks a BatchNorm's saved statistics up by image (bn.grouped); 0: one batch"
     from . import bn as _bn
     G = _bn.groups()
-    if G > 1 and (PERSISTENT or SIDE_STREAM):
-        raise RuntimeError("bn.grouped(G > 1) runs on the default kernels only (no measured alternative)")
+    if G > 1 and SIDE_STREAM:
+        raise RuntimeError("bn.grouped(G > 1) does not run with the side-stream alternative")
     return n // G if G > 1 else 0
 
 

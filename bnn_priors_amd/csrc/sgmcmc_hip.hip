@@ -1461,18 +1461,18 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "mlp_hip.inc"
 // the convolutional trunk's fp32-MFMA kernels (googleresnet gradient)
 #include "conv_hip.inc"
+#include "conv2_hip.inc"
 #include "conv_down_hip.inc"
 #include "conv50_hip.inc"
 #include "bn_hip.inc"
-// Measured alternatives that LOST to the default kernels inside the captured step (the persistent
-// convolutions on prepared weight fragments, the BatchNorm folded into the next convolution's staging, the BatchNorm
-// backward formed inside the convolution-gradient launch, the weight-gradient half on a side stream).  They are kept,
+// Measured alternatives that LOST to the default kernels (the BatchNorm folded into the next
+// convolution's staging, the BatchNorm backward formed inside the convolution-gradient launch, the weight-gradient half
+// on a side stream).  They are kept,
 // tested and switchable -- but only in a library built with -DSGMCMC_ALTERNATIVES (include/sgmcmc_hip_alternatives.h;
 // SGMCMC_ALTERNATIVES=1 in the environment of bnn_priors_amd._hip.build()): the shipped library and the header a
 // maintainer reads describe the path that runs.
 #ifdef SGMCMC_ALTERNATIVES
 #include "sgmcmc_hip_alternatives.h"
-#include "conv2_hip.inc"
 #include "conv_fused_hip.inc"
 #include "conv_fold_hip.inc"
 #endif

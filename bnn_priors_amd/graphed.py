@@ -351,7 +351,9 @@ class GraphedAccumulate:
         params = self.eng.params
         for p in params:
             p.grad = None
-        with self._logging(), _bn.grouped(group), _conv.deferring(self.model):
+        # (several minibatches per launch: the persistent convolutions, csrc/conv2_hip.inc -- see conv.persistent)
+        with self._logging(), _bn.grouped(group), _conv.persistent(group > 1 and EXACT_PERSISTENT), \
+                _conv.deferring(self.model):
             with _pool.head_loss(y, "sum", self.pot.N):
                 f = self.pot._logits(x)
             this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.pot.N)
@@ -399,6 +401,7 @@ class GraphedAccumulate:
 # ------------------------------------------------------------------ the exact pass on several streams
 EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "3"))      # streams (3 with grouped launches: 189 vs 200 ms per googleresnet pass at 2; at one minibatch per launch 2 was the optimum)
 EXACT_GROUP = int(os.environ.get("SGMCMC_EXACT_GROUP", "4"))      # minibatches per launch chain (1: one, as round 3)
+EXACT_PERSISTENT = os.environ.get("SGMCMC_EXACT_PERSISTENT", "1") != "0"     # grouped bodies on the persistent convolutions
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
 

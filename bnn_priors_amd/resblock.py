@@ -266,8 +266,8 @@ class _Block(torch.autograd.Function):
         s = _stream()
         G = ctx.groups = _bn._groups_of(x)
         if G > 1:
-            if FOLD_BN or _conv.PERSISTENT or not EPILOGUE_SUMS or _conv.SIDE_STREAM:
-                raise RuntimeError("bn.grouped(G > 1) runs on the default kernels only (no measured alternative)")
+            if FOLD_BN or not EPILOGUE_SUMS or _conv.SIDE_STREAM:
+                raise RuntimeError("bn.grouped(G > 1): only the epilogue-sums route (default or persistent convolutions)")
             _conv._note_use(g1, b1, g2, b2)
         if FOLD_BN and not _conv.PERSISTENT:
             y1, h, saved1, y2, stats2, slices = _conv_bn_conv_fwd(lib, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, s)

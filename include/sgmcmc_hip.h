@@ -428,6 +428,42 @@ int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float
                           int hw, int* deferred_slabs, void* stream);
 int sgmcmc_wrw_reduce_many(const sgmcmc_reduce_job* jobs, int n_jobs, void* stream);
 
+#define SGMCMC_FRAG_JOBS 24   /* convolutions per launch of sgmcmc_conv3x3_prepare_weights */
+/* ---- the same three contractions, PERSISTENT kernels on prepared weight fragments (csrc/conv2_hip.inc; round 3) ----
+ * Replaces the convolutions of models/google_resnet.py:11-43 inside a gradient evaluation, as sgmcmc_conv3x3 /
+ * sgmcmc_conv3x3_bwd_ex do, for the same three shapes.  WHERE THEY RUN: launches that carry several minibatches -- the
+ * grouped exact full-data pass (inference_reject.py:18-33; graphed.py), 512 and more images per launch with the SAME
+ * weights for a whole pass -- where persistent, double-buffered workgroups are 10-20 % faster (tools/conv_lab at 512
+ * images: backward 62 -> 51 us at 32 channels, 65 -> 51 us at 64; forward 35 -> 28 us at 64; the pass 190 -> 172 ms).
+ * The 128-image leapfrog step keeps sgmcmc_conv3x3[_bwd_ex] (there these are slower: 1,131 vs 1,154 steps/s,
+ * DESIGN.md section 3).  Differences:
+ *   - the weights are read as MFMA fragments that sgmcmc_conv3x3_prepare_weights leaves in caller-owned buffers of
+ *     channels^2 * 9 floats each (forward order and transposed + flipped for the data gradient): ONE launch for all
+ *     convolutions of a gradient evaluation (up to SGMCMC_FRAG_JOBS per launch; more are split over launches);
+ *   - items of 4 image rows; workgroups are persistent over a stream of items, XCD-aware (an image's items, its
+ *     channel tiles and both of its gradients are processed on XCD = image mod 8);
+ *   - statistics / backward-sum partials: [channels][sgmcmc_conv3x3_frag_stat_slices(...)][2] doubles, slice =
+ *     image * (hw / 4) + band -- equal parts, as sgmcmc_bn_train_fwd / sgmcmc_bn_bwd_dx expect;
+ *   - weight-gradient slabs: `scratch` = [channels / 16][P][9][16][channels] floats, P = *deferred_slabs: one reduction
+ *     job PER 16-output-channel tile t (part = scratch + t * P * 144 * channels, out = dw + t * 144 * channels,
+ *     numel = 144 * channels, taps = 9).  With dw != NULL and deferred_slabs == NULL the reductions are launched here.
+ * Results agree with the round-2 kernels up to fp32 summation order; runs are bitwise reproducible. */
+typedef struct sgmcmc_frag_job {
+  const float* w;  /* [channels][channels][3][3] */
+  float* fwd;      /* channels^2 * 9 floats, or NULL */
+  float* dgrad;    /* channels^2 * 9 floats, or NULL */
+  int32_t channels, reserved;
+} sgmcmc_frag_job;
+int sgmcmc_conv3x3_prepare_weights(const sgmcmc_frag_job* jobs, int n_jobs, void* stream);
+int sgmcmc_conv3x3_frag_stat_slices(int n_img, int channels, int hw);
+int64_t sgmcmc_conv3x3_frag_scratch_floats(int n_img, int channels, int hw);
+int sgmcmc_conv3x3_frag_fwd(const float* x, const float* frag_fwd, float* y, int n_img, int channels, int hw,
+                            double* stats, void* stream);
+int sgmcmc_conv3x3_frag_bwd(const float* x, const float* frag_dgrad, const float* dy, float* dx,
+                            const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
+                            int hw, int* deferred_slabs, void* stream);
+
+
 /* The two convolutions that open a down-sampling ResNet block, as one operator (they read the same input;
  * the 1x1 shortcut's operand is the 3x3's centre tap): models/google_resnet.py:77-90.
  *   y_main[n,co,oy,ox]  = sum_{ci,r,s} x[n,ci,2oy+r-1,2ox+s-1] w_main[co,ci,r,s]     (3x3, stride 2, pad 1)

@@ -9,8 +9,6 @@
  *                                        the same steps/s;
  *   - sgmcmc_conv3x3_bwd_part            the weight-gradient half of a convolution backward on a side stream: every
  *                                        fork + join edge of a replayed graph costs ~19 us, 1,137 -> 845 steps/s;
- *   - sgmcmc_conv3x3_prepare_weights /   persistent, double-buffered trunk convolutions on prepared weight fragments:
- *     _frag_fwd / _frag_bwd              1-13 % faster per launch alone, 1,154 -> 1,131 steps/s in the step;
  *   - sgmcmc_conv3x3_bn_bwd              the BatchNorm backward formed inside the convolution-gradient launch: needs a
  *                                        sums launch of its own, 1,059 vs 1,122 steps/s.
  *
@@ -21,8 +19,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-#define SGMCMC_FRAG_JOBS 24   /* convolutions per launch of sgmcmc_conv3x3_prepare_weights */
 
 /* A residual block's first BatchNorm + ReLU folded into its second convolution (models/google_resnet.py:34-43):
  *   sgmcmc_conv3x3_fx    y = conv3x3(x, w) and the batch statistics of y ADDED to `fx` -- per-XCD integer slots,
@@ -55,36 +51,6 @@ int sgmcmc_conv3x3_bnin(const float* x, const float* w, float* y, int n_img, int
 int sgmcmc_conv3x3_bwd_part(const float* x, const float* w, const float* dy, float* dx,
                             const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
                             int which, int* deferred_slabs, void* stream);
-
-/* ---- the same three contractions, PERSISTENT kernels on prepared weight fragments (csrc/conv2_hip.inc; round 3) ----
- * Replaces the convolutions of models/google_resnet.py:11-43 inside the gradient evaluation of inference.py:215-223,
- * as sgmcmc_conv3x3 / sgmcmc_conv3x3_bwd_ex do, for the same three shapes.  Differences:
- *   - the weights are read as MFMA fragments that sgmcmc_conv3x3_prepare_weights leaves in caller-owned buffers of
- *     channels^2 * 9 floats each (forward order and transposed + flipped for the data gradient): ONE launch for all
- *     convolutions of a gradient evaluation (up to SGMCMC_FRAG_JOBS per launch; more are split over launches);
- *   - items of 4 image rows; workgroups are persistent over a stream of items, XCD-aware (an image's items, its
- *     channel tiles and both of its gradients are processed on XCD = image mod 8);
- *   - statistics / backward-sum partials: [channels][sgmcmc_conv3x3_frag_stat_slices(...)][2] doubles, slice =
- *     image * (hw / 4) + band -- equal parts, as sgmcmc_bn_train_fwd / sgmcmc_bn_bwd_dx expect;
- *   - weight-gradient slabs: `scratch` = [channels / 16][P][9][16][channels] floats, P = *deferred_slabs: one reduction
- *     job PER 16-output-channel tile t (part = scratch + t * P * 144 * channels, out = dw + t * 144 * channels,
- *     numel = 144 * channels, taps = 9).  With dw != NULL and deferred_slabs == NULL the reductions are launched here.
- * Results agree with the round-2 kernels up to fp32 summation order; runs are bitwise reproducible. */
-typedef struct sgmcmc_frag_job {
-  const float* w;  /* [channels][channels][3][3] */
-  float* fwd;      /* channels^2 * 9 floats, or NULL */
-  float* dgrad;    /* channels^2 * 9 floats, or NULL */
-  int32_t channels, reserved;
-} sgmcmc_frag_job;
-int sgmcmc_conv3x3_prepare_weights(const sgmcmc_frag_job* jobs, int n_jobs, void* stream);
-int sgmcmc_conv3x3_frag_stat_slices(int n_img, int channels, int hw);
-int64_t sgmcmc_conv3x3_frag_scratch_floats(int n_img, int channels, int hw);
-int sgmcmc_conv3x3_frag_fwd(const float* x, const float* frag_fwd, float* y, int n_img, int channels, int hw,
-                            double* stats, void* stream);
-int sgmcmc_conv3x3_frag_bwd(const float* x, const float* frag_dgrad, const float* dy, float* dx,
-                            const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
-                            int hw, int* deferred_slabs, void* stream);
-
 
 /* ---- BatchNorm backward folded into the convolution's gradient launch (csrc/conv_fused_hip.inc) ----------
  * For a "conv3x3 -> BatchNorm(train) -> [+ shortcut] -> ReLU" pair of the ResNet trunk (google_resnet.py:34-43,

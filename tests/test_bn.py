@@ -297,12 +297,14 @@ def test_grouped_batchnorm_has_the_bits_of_the_groups_run_alone(G, nb, c, hw, re
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("G,nb", [(4, 128), (3, 32), (2, 5)])
-def test_grouped_gradient_evaluation_of_the_resnet_equals_the_minibatches_one_by_one(G, nb):
+def test_grouped_gradient_evaluation_of_the_resnet_equals_the_minibatches_one_by_one(G, nb, persistent):
     """the whole googleresnet under bn.grouped(G) -- fused residual blocks, down-sampling pairs with the dual BatchNorm,
     the stem, the fused head + loss, every BatchNorm backward's sums from an upstream epilogue looked up per group --
     against the G minibatches evaluated one by one: logits and logged statistics bit-identical, the summed gradient to
-    rounding (the groups' slabs are added in another order)."""
+    rounding (the groups' slabs are added in another order); on the default and on the persistent convolutions (what the
+    grouped exact pass runs, conv.persistent)."""
     import runner_cases as RC
     from bnn_priors_amd import conv, models, pool
     g = torch.Generator().manual_seed(77)
@@ -321,7 +323,7 @@ def test_grouped_gradient_evaluation_of_the_resnet_equals_the_minibatches_one_by
                  for i, m in enumerate(bns)}
         for p in params:
             p.grad = None
-        with bn.logging_running_stats(slots), bn.grouped(groups), conv.deferring(model):
+        with bn.logging_running_stats(slots), bn.grouped(groups), conv.persistent(persistent), conv.deferring(model):
             with pool.head_loss(ys, "sum", N):
                 f = model.net(xs)
             loss = pool.cross_entropy_backward(f, ys, reduction="sum", divide_by=N)

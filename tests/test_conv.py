@@ -38,7 +38,7 @@ def test_supported_is_false_off_the_table():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("persistent", [False, pytest.param(True, marks=ALT)])
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("c,hw", SHAPES)
 @pytest.mark.parametrize("n", [128, 5, 1])
 def test_kernels_match_float64_reference(c, hw, n, persistent, monkeypatch):
@@ -205,7 +205,7 @@ def test_resnet_layers_take_the_kernel_path(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("persistent", [False, pytest.param(True, marks=ALT)])
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("c,hw", SHAPES)
 def test_epilogue_statistics_feed_the_batchnorm(c, hw, persistent, monkeypatch):
     "conv3x3(want_stats=True): per-band sums of y; bn_train(stats=...) == bn_train() on the same y"

@@ -116,10 +116,15 @@ def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(mod
     buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
     results = []
     # one stream, minibatch by minibatch | two streams | ... with 3 (2 groups + 1 left over) and 4 minibatches per launch |
-    # one stream with 4 per launch
-    for lanes, group, batches in ((1, 1, list(train)), (2, 1, source), (2, 3, source), (2, 4, source), (1, 4, source)):
+    # one stream with 4 per launch -- all on the default convolutions: running statistics BIT-IDENTICAL | the product's
+    # default: grouped launches on the persistent convolutions (another summation order inside a convolution: the batch
+    # statistics, hence the running statistics, agree to float32 rounding)
+    configs = ((1, 1, False, list(train)), (2, 1, False, source), (2, 3, False, source), (2, 4, False, source),
+               (1, 4, False, source), (3, 4, True, source))
+    for lanes, group, persistent, batches in configs:
         monkeypatch.setattr(graphed, "EXACT_LANES", lanes)
         monkeypatch.setattr(graphed, "EXACT_GROUP", group)
+        monkeypatch.setattr(graphed, "EXACT_PERSISTENT", persistent)
         pot._exact_acc = None
         with torch.no_grad():
             for k, v in model.state_dict().items():
@@ -135,13 +140,21 @@ def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(mod
         if (lanes, group) != (1, 1):
             assert pot._exact_acc.group == group
         results.append(outs)
-    for other in results[1:]:
+    for (lanes, group, persistent, _), other in zip(configs[1:], results[1:]):
         for (l1, u1, g1, b1), (l2, u2, g2, b2) in zip(results[0], other):
-            assert abs(l1 - l2) <= 1e-9 * abs(l1) and abs(u1 - u2) <= 1e-9 * abs(u1)
+            tol = 1e-6 if persistent else 1e-9
+            assert abs(l1 - l2) <= tol * abs(l1) and abs(u1 - u2) <= tol * abs(u1)
             for a, b in zip(g1, g2):
-                torch.testing.assert_close(a, b, rtol=0, atol=2e-6 * max(1e-30, b.abs().max().item()))
+                # (another kernel generation rounds the activations differently, and at a random initialisation this net's
+                # gradient moves by 0.6 % under a one-ulp change -- DESIGN.md section 3: across generations only a sanity
+                # bound; the exact statement -- grouped = the minibatches one by one on the SAME kernels, to rounding --
+                # is tests/test_bn.py::test_grouped_gradient_evaluation_of_the_resnet_equals_the_minibatches_one_by_one)
+                torch.testing.assert_close(a, b, rtol=0, atol=(2e-2 if persistent else 2e-6) * max(1e-30, b.abs().max().item()))
             assert sorted(b1) == sorted(b2)
             for k in b1:
-                assert torch.equal(b1[k], b2[k]), k
+                if persistent and b1[k].is_floating_point():
+                    torch.testing.assert_close(b1[k], b2[k], rtol=2e-6, atol=1e-7, msg=k)
+                else:
+                    assert torch.equal(b1[k], b2[k]), (k, lanes, group)
     if buffers:      # the statistics did advance (8 minibatches per pass)
         assert any(not torch.equal(results[0][0][3][k], buffers[k]) for k in buffers)

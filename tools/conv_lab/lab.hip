@@ -9,6 +9,7 @@
 #include <vector>
 #include <algorithm>
 #include "sgmcmc_hip.h"
+#include "sgmcmc_hip_alternatives.h"   // (the lab compares the default kernels with the measured alternatives)
 
 namespace sgmcmc_timing { static hipEvent_t e0 = nullptr, e1 = nullptr; }
 #define SGMCMC_LAUNCH(kernel, grid, block, lds, stream, ...)                                           \
