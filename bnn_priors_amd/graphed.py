@@ -439,7 +439,8 @@ class ConcurrentAccumulate:
             G -= 1
         self.group = G = max(G, 1)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        self.lanes, self.singles, self.log_cur, self.log_cur1 = [], [], [], []
+        self.lanes, self.singles, self.log_cur, self.log_cur1, self.slots1 = [], [], [], [], []
+        self.off_shape = {}          # (lane, shapes) -> a captured body for a minibatch of another size (the ragged last one)
         main = torch.cuda.current_stream(dev)
         nb, cm = max(self.n_bn, 1), self.cmax
         for s in self.streams:
@@ -450,6 +451,7 @@ class ConcurrentAccumulate:
                 single = GraphedAccumulate(potential, optimizer, x_example, y_example, log_slots=slots1)
                 self.singles.append(single)
                 self.log_cur1.append(cur1)
+                self.slots1.append(slots1)
                 if G > 1:
                     cur = torch.zeros((G, nb, cm, 2), dtype=torch.float64, device=dev)
                     slots = {id(m.running_mean): cur[:, i, :m.num_features] for i, m in enumerate(self.bn_layers)}
@@ -521,9 +523,10 @@ class ConcurrentAccumulate:
                         break
                     finally:
                         target["dst"] = None
-                    if self.matches(x, y):
+                    body = single if self.matches(x, y) else self._off_shape_body(k, x, y)
+                    if body is not None:
                         turn += 1
-                        single.add(x, y)
+                        body.add(x, y)
                         if self.n_bn:
                             self.log_all[self.count - self.logged_from].copy_(self.log_cur1[k], non_blocking=True)
                         self.count += 1
@@ -540,6 +543,24 @@ class ConcurrentAccumulate:
                 for s in self.streams:
                     s.wait_stream(torch.cuda.current_stream(self.dev))
         self._join_and_replay()
+
+    def _off_shape_body(self, k, x, y):
+        """a captured body for a minibatch of another size on lane k -- the ragged last minibatch of every pass, which ran
+        eagerly (~90 launches from Python, 3-4 ms, behind a join of all lanes) until round 4; it is logged and replayed
+        like any other minibatch.  At most two shapes per lane are captured; None = evaluate eagerly as before."""
+        if not (x.is_cuda and y.is_cuda and x.shape[0] > 0):
+            return None
+        key = (k, tuple(x.shape), tuple(y.shape), x.dtype)
+        body = self.off_shape.get(key)
+        if body is None:
+            if sum(1 for q in self.off_shape if q[0] == k) >= 2:
+                return None
+            try:
+                body = GraphedAccumulate(self.pot, self.opt, x, y, log_slots=self.slots1[k], share=self.singles[k])
+            except RuntimeError:
+                body = False
+            self.off_shape[key] = body
+        return body or None
 
     def _join_and_replay(self):
         "lanes joined into the current stream; the running statistics advanced by the minibatches logged since the last join"
