@@ -16,6 +16,6 @@ done
 cd $REPO
 F=$(find $OUT/$NAME.FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/$NAME.WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python tools/pmc_hbm_summary.py "$F" "$W" --tail $TAIL > $OUT/${NAME}_pmc_hbm.txt
+python tools/pmc_hbm_summary.py "$F" "$W" --tail $TAIL $PMC_SUMMARY_ARGS > $OUT/${NAME}_pmc_hbm.txt
 find $OUT/$NAME.FETCH_SIZE $OUT/$NAME.WRITE_SIZE -name '*.csv' -size +8M -delete   # keep scratch small
 cat $OUT/${NAME}_pmc_hbm.txt

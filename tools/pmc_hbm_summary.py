@@ -29,8 +29,18 @@ def load(path, counter):
     return rows
 
 
+BN_SHAPE = None      # (n, channels, side) of the one stage tools/bn_pmc.py ran (--bn-shape): the names do not carry it
+
+
 def algorithmic_bytes(name, grid):
     "bytes one launch has to move at least once (reads, writes), or None"
+    m = re.search(r"bn::(apply_kernel|bwd_dx_kernel)<(true|false), (true|false)", name)
+    if m and BN_SHAPE:
+        n, c, hw = BN_SHAPE
+        act = 4 * n * c * hw * hw
+        if m.group(1) == "apply_kernel":      # reads x (+ residual), writes y
+            return act * (2 if m.group(3) == "true" else 1), act
+        return 3 * act, act                   # reads dout, out (ReLU mask), x; writes dx
     m = re.search(r"step_kernel(_stream|_indirect)?<float, \d+(, (true|false), (\d))?", name)
     if m:                                  # 28 B per element: 4 reads + 3 writes of 4 B
         items = 4 if (m.group(1) == "_stream" or m.group(4) is None) else int(m.group(4))
@@ -69,7 +79,11 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("--tail", type=float, default=0.5)
     ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--bn-shape", default=None, help="n,channels,side of the BatchNorm stage of tools/bn_pmc.py")
     a = ap.parse_args()
+    global BN_SHAPE
+    if a.bn_shape:
+        BN_SHAPE = tuple(int(v) for v in a.bn_shape.split(","))
     fetch, write = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
     print(f"dispatches with FETCH_SIZE: {len(fetch)}, with WRITE_SIZE: {len(write)}; tail {a.tail:g} summarised")
     agg = collections.OrderedDict()
