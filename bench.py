@@ -710,7 +710,22 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     n_params = sum(p.numel() for p in model.parameters())
     pool = PoolSource(args.workload, N, device, 1234 + rank)   # the whole synthetic data set, in HBM
-    loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
+    # The conv nets read their minibatches through the PRODUCT's batch source (inference._BatchSource over a shuffling
+    # DataLoader of the HBM-resident set; googleresnet: augmented on read) -- a fresh permutation per epoch, every
+    # minibatch gathered (+ cropped / flipped) inside the captured step's one staging launch (LazyBatch), the exact pass
+    # filling its bodies' static inputs in place: what a user's run executes.  The dense net keeps its index batches.
+    product_source = args.workload != "densenet"
+    augment = None
+    if product_source:
+        if args.workload == "googleresnet" and args.augment:
+            from bnn_priors_amd.augment import AugmentedTensorDataset, RandomCropFlip
+            augment = RandomCropFlip(pad=4, flip=True, seed=1234, stream=rank)
+            dataset = AugmentedTensorDataset(pool.x, pool.y, augment)
+        else:
+            dataset = torch.utils.data.TensorDataset(pool.x, pool.y)
+        loader = torch.utils.data.DataLoader(dataset, batch_size=128, shuffle=True)
+    else:
+        loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
     empty_test = torch.utils.data.DataLoader(_SyntheticSet(0), batch_size=128)
     extra = {}
     if hmc and args.trajectory:
@@ -725,28 +740,29 @@ def main():
         sampling_decay="cosine", cycles=60, precond_update=1, metrics_saver=MemoryMetrics(),
         model_saver=None, reject_samples=args.inference != "SGLDReject", seed=1234, chain_id=rank, **extra)
     # the exact initial gradient over the synthetic pool stands in for the full-data pass
-    runner._batch_source = pool
+    if not product_source:
+        runner._batch_source = pool
     runner.use_graph = not args.eager
     step = runner.begin()
     eng = runner.optimizer.engine
     fused = runner._fused_dense() is not None
-    batches = list(pool.index_batches()) if fused else list(pool)
-    batches = [b for b in batches if len(b[0]) == 128]       # the L-th minibatch is ragged (N % 128)
-    augment = None
-    if args.workload == "googleresnet" and args.augment and not fused:
-        from bnn_priors_amd.augment import RandomCropFlip
-        augment = RandomCropFlip(pad=4, flip=True, seed=1234, stream=rank)
-        rows = [torch.arange(128 * b, 128 * (b + 1), device=device) for b in range(len(batches))]
+    source = runner._batches()
     path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
-            "eager" if args.eager else "hipGraph of autograd fwd/bwd (hand-written conv / BN kernels) + fused sampler")
+            "eager" if args.eager else "hipGraph of autograd fwd/bwd (hand-written conv / BN kernels) + fused sampler; "
+            "minibatch gather (+ augmentation) + argument block + deferred bookkeeping in one launch between replays")
+
+    def full_batches():
+        "the runner's own hot-loop batch stream, epoch after epoch, without the ragged last minibatch (N % 128)"
+        while True:
+            for xb, yb in runner._hot_batches():
+                if len(xb) == 128:
+                    yield xb, yb
+    stream_of_batches = full_batches()
 
     def run(k, step):
         for _ in range(k):
             step += 1
-            b = step % len(batches)
-            x, y = batches[b]
-            if augment is not None:     # a fresh crop / flip of every image at every visit (draw = the pass counter)
-                x = augment.gather(pool.x, rows[b], step // len(batches))
+            x, y = next(stream_of_batches)
             runner.leapfrog(step, x, y, last_of_epoch=False)
         return step
 
@@ -796,7 +812,7 @@ def main():
     if not args.no_kernel_timing:
         opt = runner.optimizer
         if any(p.grad is None for p in eng.params):
-            x, y = next(iter(pool))
+            x, y = next(iter(source))
             runner._model_potential_and_grad(x, y, False)
         eng.start_kernel_timing()
         for _ in range(200):
@@ -807,18 +823,15 @@ def main():
         # one stored sample = L leapfrog steps + the runner's own M-H point (inference_reject.py:115-157: exact
         # full-data gradient, final_step, energy difference, M-H test, metrics row, momentum refresh for HMC,
         # initial_step) -- timed end to end, K times, through the SAME method the runner's loop calls
-        all_b = list(pool.index_batches()) if fused else list(pool)
-        rows_all = [torch.arange(128 * b, min(128 * (b + 1), N), device=device) for b in range(len(all_b))]
+        n_b = len(source)
 
         def one_sample(step, save=None):
             acc = 0.0
-            for i, (x, y) in enumerate(all_b):
+            for i, (x, y) in enumerate(runner._hot_batches()):        # one epoch of the runner's own batch stream
                 step += 1
-                if augment is not None:
-                    x = augment.gather(pool.x, rows_all[i], step // len(all_b))
-                acc = runner.leapfrog(step, x, y, last_of_epoch=(i == len(all_b) - 1))
+                acc = runner.leapfrog(step, x, y, last_of_epoch=(i == n_b - 1))
             runner._drain_rows()
-            return runner._mh_point(step, acc, pool, save=save)
+            return runner._mh_point(step, acc, source, save=save)
 
         def timed_samples(save=None):
             s = one_sample(step, save)          # untimed: first use of this variant's launches

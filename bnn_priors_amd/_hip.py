@@ -108,6 +108,14 @@ class BnDual(ctypes.Structure):
                 + [("log_stride", ctypes.c_int64)])
 
 
+class Gather(ctypes.Structure):
+    "sgmcmc_gather"
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("data", "labels", "idx", "out", "labels_out", "fill")]
+                + [(n, ctypes.c_int32) for n in ("batch", "channels", "height", "width", "pad", "flip")]
+                + [("seed", ctypes.c_uint64), ("draw", ctypes.c_uint64), ("stream", ctypes.c_uint32),
+                   ("reserved", ctypes.c_uint32)])
+
+
 class BnReplayLayer(ctypes.Structure):
     "sgmcmc_bn_replay_layer"
     _fields_ = [("log", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
@@ -276,6 +284,8 @@ EXPORTS = {
                                 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_bn_bwd_dx": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
                          + [ctypes.c_void_p] * 3 + [ctypes.POINTER(BnResidualSums), ctypes.c_int, ctypes.c_void_p]),
+    "sgmcmc_gather_stage": (ctypes.c_int, [ctypes.POINTER(Gather)] + [ctypes.c_void_p] * 3
+                            + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sgmcmc_stage_batch": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
     "sgmcmc_bn_bwd_sums": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 4

@@ -141,7 +141,18 @@ class GraphedLeapfrog(_ReportSlots):
         if ev is not None:
             ev.synchronize()            # the copy that last used this slot has executed
         ctypes.memmove(self._slots[i].data_ptr(), ctypes.addressof(A), ctypes.sizeof(A))
-        stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i], self.eng)
+        if y is None and x is not None and hasattr(x, "stage"):
+            # a LazyBatch: gathered (and augmented) straight into the static inputs by the launch that also copies the
+            # argument block and runs the previous transition's deferred bookkeeping
+            eng = self.eng
+            pending, eng.pending = eng.pending, None
+            slot = self._slots[i]
+            jobs = [(slot.data_ptr(), self.args_dev.data_ptr(), slot.numel())] if slot.numel() % 4 == 0 else []
+            if not jobs:
+                self.args_dev.copy_(slot, non_blocking=True)
+            x.stage(self.x, self.y, jobs, eng.layout, pending, torch.cuda.current_stream(self.x.device).cuda_stream)
+        else:
+            stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i], self.eng)
         ev = self._slot_events[i] = ev or torch.cuda.Event()
         ev.record()
 

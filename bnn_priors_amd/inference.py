@@ -16,6 +16,7 @@ What differs, by design (DESIGN.md "Runner"):
 """
 import contextlib
 import math
+import os
 
 import torch
 
@@ -53,6 +54,91 @@ class LambdaSchedule:
 def _is_hmc(optimizer):
     "momentum is fully refreshed before every initial step for HMC only (inference.py:312-315)"
     return isinstance(optimizer, mcmc.HMC) or getattr(optimizer, "is_hmc", False)
+
+
+@contextlib.contextmanager
+def _serial_cpu():
+    """The host-side tensor work of a batch source (a permutation of N indices, a seed draw) with ONE intra-op thread.
+    torch sizes its CPU thread pool by the machine (256 on the MI355X hosts) whatever share of it the process may use: a
+    parallel region that wakes such a pool in the middle of a pass stalled the launching thread for 45-100 ms now and
+    then (the convolutional classifier's exact pass: 31 ms -> 77-126 ms, every other pass; OMP_NUM_THREADS <= 8: gone)."""
+    old = torch.get_num_threads()
+    if old > 1:
+        torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        if old > 1:
+            torch.set_num_threads(old)
+
+
+class LazyBatch:
+    """A minibatch that is not gathered yet: rows ``idx`` (device int64) of a device-resident data set, with the
+    augmentation draw of its traversal.  ``materialize()`` gathers it into new tensors -- what the batch source would have
+    yielded; ``stage(...)`` gathers it straight into a captured step's static inputs in the SAME launch that copies the
+    step's argument block and runs the previous transition's deferred bookkeeping (csrc/augment_hip.inc,
+    gather_stage_kernel): one launch between two graph replays instead of gather + label index_select + staging copy."""
+    __slots__ = ("src", "idx", "draw")
+
+    def __init__(self, src, idx, draw):
+        self.src, self.idx, self.draw = src, idx, draw
+
+    def __len__(self):
+        return self.idx.numel()
+
+    @property
+    def shapes(self):
+        "(x shape, y shape) of the materialised minibatch"
+        return (len(self),) + tuple(self.src.x.shape[1:]), (len(self),) + tuple(self.src.y.shape[1:])
+
+    def materialize(self):
+        s = self.src
+        if s.augment is not None:
+            return s.augment.gather(s.x, self.idx, self.draw), s.y.index_select(0, self.idx)
+        return s.x.index_select(0, self.idx), s.y.index_select(0, self.idx)
+
+    def stageable(self, x_dst, y_dst):
+        s = self.src
+        return (s.x.dtype == torch.float32 and s.x.is_contiguous() and s.y.dtype == torch.int64 and s.y.dim() == 1
+                and x_dst.dtype == torch.float32 and y_dst.dtype == torch.int64 and x_dst.is_contiguous()
+                and y_dst.is_contiguous() and (tuple(x_dst.shape), tuple(y_dst.shape)) == self.shapes)
+
+    def stage(self, x_dst, y_dst, jobs, layout, pending, stream):
+        """x_dst / y_dst <- this minibatch; ``jobs``: up to three (src_ptr, dst_ptr, bytes) plain copies riding along;
+        ``pending`` (with ``layout``): a transition whose deferred bookkeeping runs in the same launch, or None"""
+        import ctypes
+        from . import _hip
+        s, aug = self.src, self.src.augment
+        shape = tuple(s.x.shape[1:])
+        if aug is not None and len(shape) == 3:
+            c, h, w = shape
+            pad, flip, seed, strm = aug.pad, int(aug.flip), aug.seed & (2 ** 64 - 1), aug.stream
+            fill = 0
+            if aug.fill is not None:
+                if aug.fill.device != s.x.device:
+                    aug.fill = aug.fill.to(s.x.device)
+                fill = aug.fill.data_ptr()
+        else:
+            row = 1
+            for d in shape:
+                row *= d
+            c, h, w, pad, flip, seed, strm, fill = 1, 1, row, 0, 0, 0, 0, 0
+        G = _hip.Gather(data=s.x.data_ptr(), labels=s.y.data_ptr(), idx=self.idx.data_ptr(), out=x_dst.data_ptr(),
+                        labels_out=y_dst.data_ptr(), fill=fill, batch=len(self), channels=c, height=h, width=w, pad=pad,
+                        flip=flip, seed=seed, draw=int(self.draw or 0), stream=strm, reserved=0)
+        n = len(jobs)
+        arr = lambda vals, t: (t * max(n, 1))(*vals) if n else None
+        err = _hip.lib().sgmcmc_gather_stage(ctypes.byref(G), arr([j[0] for j in jobs], ctypes.c_void_p),
+                                             arr([j[1] for j in jobs], ctypes.c_void_p),
+                                             arr([j[2] for j in jobs], ctypes.c_int64), n,
+                                             ctypes.byref(layout) if pending is not None else None,
+                                             ctypes.byref(pending) if pending is not None else None, stream)
+        if err:
+            _hip.check(err, "sgmcmc_gather_stage")
+
+
+# minibatches handed to a captured step as LazyBatch objects (one launch between two replays); 0: gathered tensors
+LAZY_BATCHES = os.environ.get("SGMCMC_LAZY_BATCH", "1") != "0"
 
 
 class _BatchSource:
@@ -132,7 +218,8 @@ class _BatchSource:
         (the reject runner's per-cycle generator) that draw decides the batch composition of the
         next pass, which BatchNorm nets feel; reproduce it."""
         if gen is not None:
-            torch.randperm(len(self.dl.dataset), generator=gen)
+            with _serial_cpu():
+                torch.randperm(len(self.dl.dataset), generator=gen)
 
     def __iter__(self):
         return self._iterate(False)
@@ -142,7 +229,12 @@ class _BatchSource:
         so that a kernel can gather them itself; falls back to tensors when not ``fast``"""
         return self._iterate(True)
 
-    def _iterate(self, by_index):
+    def lazy_batches(self):
+        """same minibatches, same RNG consumption, but as ``LazyBatch`` objects (x still in the data set): the consumer
+        gathers them where it wants them (``LazyBatch.stage``); falls back to tensors when not ``fast``"""
+        return self._iterate(False, lazy=True)
+
+    def _iterate(self, by_index, lazy=False):
         if not self.fast:
             for x, y in self.dl:
                 yield x.to(self.device), y.to(self.device)
@@ -151,8 +243,9 @@ class _BatchSource:
         # DataLoader.__iter__ draws a worker base seed before the sampler runs
         # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__): keep the global
         # RNG stream aligned with a run that iterates the DataLoader itself
-        torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
-        perm, gen = self._permutation()
+        with _serial_cpu():
+            torch.empty((), dtype=torch.int64).random_(generator=self.dl.generator)
+            perm, gen = self._permutation()
         stop = n - n % bs if self.dl.drop_last else n
         if self.augment is not None:
             draw = self.dl.dataset.next_draw()
@@ -160,6 +253,9 @@ class _BatchSource:
             order = order.to(self.device)
             for i in range(0, stop, bs):
                 idx = order[i:i + bs]
+                if lazy:
+                    yield LazyBatch(self, idx, draw), None
+                    continue
                 xd, yd = self._dst(idx.numel())
                 yield (self.augment.gather(self.x, idx, draw, out=xd),
                        self.y.index_select(0, idx) if yd is None else torch.index_select(self.y, 0, idx, out=yd))
@@ -174,6 +270,12 @@ class _BatchSource:
             return
         if perm is not None:
             perm = perm.to(self.device)
+        if lazy:
+            order = perm if perm is not None else torch.arange(n, device=self.device)
+            for i in range(0, stop, bs):
+                yield LazyBatch(self, order[i:i + bs], None), None
+            self._exhausted(gen)
+            return
         for i in range(0, stop, bs):
             xd, yd = self._dst(min(bs, n - i))
             if perm is None:
@@ -288,6 +390,9 @@ class SGLDRunner:
         src = self._batches()
         if self._fused_dense() is not None and hasattr(src, "index_batches"):
             return src.index_batches()
+        if (LAZY_BATCHES and self.use_graph and self._graphed is not False and getattr(src, "fast", False)
+                and hasattr(src, "lazy_batches")):
+            return src.lazy_batches()       # gathered inside the captured step's one staging launch (LazyBatch.stage)
         return iter(src)
 
     def _graph_for(self, x, y):
@@ -306,6 +411,19 @@ class SGLDRunner:
             self._graphed = GraphedLeapfrog(pot, self.optimizer, x, y)
         return self._graphed if self._graphed.matches(x, y) else None
 
+    def _graph_for_lazy(self, batch):
+        "the captured graph for a LazyBatch it can gather into its static inputs itself, else None"
+        if not self.use_graph or self._graphed is False:
+            return None
+        if self._graphed is None:
+            x, y = batch.materialize()          # (the capture needs tensors once)
+            if self._graph_for(x, y) is None:
+                return None
+        g = self._graphed
+        if g in (None, False) or g.shape != batch.shapes or not batch.stageable(g.x, g.y):
+            return None
+        return g
+
     @staticmethod
     def _tensors_of(x, y):
         return x.materialize() if y is None else (x, y)
@@ -317,11 +435,19 @@ class SGLDRunner:
         potential, energy) -- LATER: the read-back is asynchronous (one copy into a pinned slot,
         guarded by an event) so that logging never stalls the launch pipeline; rows are drained
         in order before anything else logs, evaluates or changes the sampler state."""
-        by_index = y is None          # an IndexBatch from _BatchSource.index_batches()
-        if by_index and self._fused_dense() is None:
-            x, y = x.materialize()
+        by_index = y is None          # an IndexBatch from _BatchSource.index_batches(), or a LazyBatch
+        lazy = by_index and isinstance(x, LazyBatch)
+        if lazy:
             by_index = False
-        graphed = self._fused_dense() if by_index else self._graph_for(x, y)
+            graphed = self._graph_for_lazy(x)
+            if graphed is None:
+                x, y = x.materialize()
+                graphed = self._graph_for(x, y)
+        else:
+            if by_index and self._fused_dense() is None:
+                x, y = x.materialize()
+                by_index = False
+            graphed = self._fused_dense() if by_index else self._graph_for(x, y)
         if graphed is None:
             return False, x, y
         if not store:

@@ -725,6 +725,26 @@ int sgmcmc_augment_gather(const float* data, const int64_t* idx, float* out, con
                           int channels, int height, int width, int pad, int flip, uint64_t seed,
                           uint32_t stream, uint64_t draw, void* stream_);
 
+/* Round 4: everything between two replays of a captured step in ONE launch -- sgmcmc_augment_gather into `out` (the
+ * graph's static input; pad = 0, flip = 0, channels = height = 1: a plain row gather), the labels gathered beside it
+ * (labels_out[b] = labels[idx[b]]; both NULL: none), up to three plain copies as sgmcmc_stage_batch (the argument block
+ * from its pinned slot; n_copies may be 0) and the previous transition's deferred bookkeeping (A_pending, as
+ * sgmcmc_stage_batch).  Replaces the DataLoader hand-over of inference.py:197-205 + data/CIFAR/cifar.py:136-172 for a
+ * captured step: 1 launch instead of 3 (gather, label index_select, staging copy). */
+typedef struct sgmcmc_gather {
+  const float* data;          /* [rows][channels][height][width] */
+  const int64_t* labels;      /* [rows] or NULL */
+  const int64_t* idx;         /* [batch] data-set rows */
+  float* out;                 /* [batch][channels][height][width] */
+  int64_t* labels_out;        /* [batch] or NULL */
+  const float* fill;          /* [channels] or NULL */
+  int32_t batch, channels, height, width, pad, flip;
+  uint64_t seed, draw;
+  uint32_t stream, reserved;
+} sgmcmc_gather;
+int sgmcmc_gather_stage(const sgmcmc_gather* G, const void* const* src, void* const* dst, const int64_t* bytes,
+                        int n_copies, const sgmcmc_layout* L, const sgmcmc_step_args* A_pending, void* stream);
+
 /* Up to three plain device copies in ONE launch: dst[j][0 .. bytes[j]) = src[j][...].  For the per-step staging of a
  * captured step -- the minibatch (x, y) into the graph's static inputs and the argument block from PINNED host
  * memory (the kernel reads it over the bus) -- which otherwise costs three copy dispatches between two graph

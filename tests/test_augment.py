@@ -184,3 +184,47 @@ def test_stage_batch_copies_up_to_three_buffers_in_one_launch_bit_exactly():
     src = (ctypes.c_void_p * 1)(x.data_ptr())
     nb = (ctypes.c_int64 * 1)(63)
     assert _hip.lib().sgmcmc_stage_batch(src, dst, nb, 1, None, None, 0) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("augmented", [True, False])
+def test_lazy_batches_staged_in_one_launch_are_the_gathered_tensors_bit_for_bit(augmented):
+    """LazyBatch.stage (gather [+ crop / flip] + labels + riding copies in ONE launch: csrc/augment_hip.inc,
+    gather_stage_kernel) leaves exactly what the batch source's ordinary iteration yields -- same rows, same draw --
+    for image sets with augmentation and for plain row gathers (flattened MNIST-shaped rows), ragged last batch
+    included, and consumes the loader's RNG identically."""
+    from bnn_priors_amd.inference import LazyBatch, _BatchSource
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    n = 300
+    x = (torch.randn(n, 3, 32, 32, generator=g) if augmented else torch.rand(n, 784, generator=g)).to(dev)
+    y = torch.randint(0, 10, (n,), generator=g).to(dev)
+
+    def source():
+        if augmented:
+            ds = augment.AugmentedTensorDataset(x, y, augment.RandomCropFlip(pad=4, flip=True, seed=11, stream=2,
+                                                                             fill=[0.1, -0.2, 0.3]))
+        else:
+            ds = torch.utils.data.TensorDataset(x, y)
+        return _BatchSource(torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True), torch.device(dev))
+
+    torch.manual_seed(5)
+    plain = [(a.clone(), b.clone()) for a, b in source()]
+    state_after = torch.get_rng_state()
+    torch.manual_seed(5)
+    lazies = list(source().lazy_batches())
+    assert torch.equal(torch.get_rng_state(), state_after)                  # same RNG consumption
+    assert [len(b) for b, _ in lazies] == [128, 128, 44] and all(t is None for _, t in lazies)
+    extra_src = torch.arange(64, dtype=torch.float32, device=dev)
+    for (lb, _), (px, py) in zip(lazies, plain):
+        assert isinstance(lb, LazyBatch) and lb.shapes == (tuple(px.shape), tuple(py.shape))
+        mx, my = lb.materialize()
+        assert torch.equal(mx, px) and torch.equal(my, py)
+        xd, yd = torch.full_like(px, -7.0), torch.full_like(py, -7)
+        extra_dst = torch.zeros_like(extra_src)
+        assert lb.stageable(xd, yd)
+        lb.stage(xd, yd, [(extra_src.data_ptr(), extra_dst.data_ptr(), extra_src.numel() * 4)], None, None,
+                 torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(xd, px) and torch.equal(yd, py) and torch.equal(extra_dst, extra_src)
+        lb.stage(xd.zero_(), yd.zero_(), [], None, None, torch.cuda.current_stream().cuda_stream)      # no riders
+        assert torch.equal(xd, px) and torch.equal(yd, py)

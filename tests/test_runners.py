@@ -367,3 +367,36 @@ def test_chains_interleaved_on_streams_equal_chains_run_alone(name):
         for k in p0:
             assert torch.equal(p0[k], p1[k]), (chain, k)
     assert not np.array_equal(alone[0][0]["potential"][1], alone[1][0]["potential"][1])     # the chains do differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["VerletSGLDReject_googleresnet", "VerletSGLDReject_convnet_laplace", "VerletSGLD"])
+def test_lazy_batches_in_the_captured_step_change_nothing(name, monkeypatch):
+    """minibatches gathered inside the captured step's one staging launch (inference.LazyBatch, the default) against
+    minibatches gathered by the batch source and copied in: same metric streams, same samples, same bits"""
+    outs = []
+    for lazy in (True, False):
+        monkeypatch.setattr(inference, "LAZY_BATCHES", lazy)
+        cfg = RC.CASES[name]
+        dev = "cuda:0"
+        train, test, (x, y) = RC.make_data(dev, cfg=cfg)
+        model = RC.make_net(models, x, y, device=dev, cfg=cfg)
+        metrics = MemoryMetrics()
+        torch.manual_seed(RC.SEED)
+        runner = _runner_class(name)(
+            model=model, dataloader=train, dataloader_test=test, learning_rate=cfg["lr"],
+            temperature=cfg["temperature"], momentum=cfg["momentum"], reject_samples=cfg["reject_samples"],
+            metrics_saver=metrics, model_saver=None, seed=RC.SEED, chain_id=0, **RC.run_kw(cfg),
+            **({"cycle_seed": RC.CYCLE_SEED} if "Reject" in name else {}))
+        runner._fused = False          # (the dense classifier: the generic captured-autograd path)
+        runner.run()
+        assert runner._graphed not in (None, False)
+        outs.append((RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}))
+    (s0, p0), (s1, p1) = outs
+    assert sorted(s0) == sorted(s1)
+    for k in s0:
+        if k == "timestamps":
+            continue
+        assert np.array_equal(s0[k][0], s1[k][0]) and np.array_equal(s0[k][1], s1[k][1]), k
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
