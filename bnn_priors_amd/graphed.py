@@ -411,7 +411,30 @@ class GraphedAccumulate:
 
 # ------------------------------------------------------------------ the exact pass on several streams
 EXACT_LANES = int(os.environ.get("SGMCMC_EXACT_LANES", "3"))      # streams (3 with grouped launches: 189 vs 200 ms per googleresnet pass at 2; at one minibatch per launch 2 was the optimum)
-EXACT_GROUP = int(os.environ.get("SGMCMC_EXACT_GROUP", "4"))      # minibatches per launch chain (1: one, as round 3)
+# minibatches per launch chain: a number (1: one, as round 3), or "auto": 4 .. 8, preferring a count that divides the
+# pass's full-size minibatches (no left-over one-minibatch replays) and deals the groups evenly to the lanes
+EXACT_GROUP = os.environ.get("SGMCMC_EXACT_GROUP", "auto")
+EXACT_GROUP = EXACT_GROUP if EXACT_GROUP == "auto" else int(EXACT_GROUP)
+
+
+def pick_group(n_full, rows, lanes, want=None):
+    "minibatches per replay for a pass of ``n_full`` full-size minibatches of ``rows`` rows on ``lanes`` streams"
+    want = EXACT_GROUP if want is None else want
+    cap = max(1, 1024 // max(rows, 1))            # (the fused head + loss launch takes up to 1,024 rows)
+    if want != "auto":
+        return max(1, min(int(want), cap))
+    if not n_full or n_full < 8:
+        return max(1, min(4, cap, n_full or 4))
+    best, best_key = 1, None
+    for g in range(min(8, cap), 0, -1):
+        if g < 4 and best_key is not None:
+            break
+        groups, left = divmod(n_full, g)
+        # fewest left-over minibatches, then evenly dealt groups, then the smaller group (less memory; 4 .. 8 measure alike)
+        key = (left, (-groups) % max(lanes, 1), g)
+        if best_key is None or key < best_key:
+            best, best_key = g, key
+    return best
 EXACT_PERSISTENT = os.environ.get("SGMCMC_EXACT_PERSISTENT", "1") != "0"     # grouped bodies on the persistent convolutions
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
@@ -434,7 +457,7 @@ class ConcurrentAccumulate:
     A batch source that can fill buffers in place (``_BatchSource.filling``) writes every minibatch straight into the
     static inputs of the body that evaluates it: no staging copy."""
 
-    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=None, group=None):
+    def __init__(self, potential, optimizer, x_example, y_example, lanes=2, capacity=None, group=None, n_full=None):
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.model = potential.model
         dev = self.dev = self.eng.device
@@ -444,11 +467,7 @@ class ConcurrentAccumulate:
             raise _bn.LogModeUnsupported("cumulative-average BatchNorm")
         self.cmax = max([m.num_features for m in self.bn_layers], default=1)
         self.n_bn = len(self.bn_layers)
-        G = EXACT_GROUP if group is None else int(group)
-        rows = x_example.shape[0]
-        while G > 1 and G * rows > 1024:       # (the fused head + loss launch takes up to 1,024 rows)
-            G -= 1
-        self.group = G = max(G, 1)
+        self.group = G = pick_group(n_full, x_example.shape[0], lanes, group)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self.lanes, self.singles, self.log_cur, self.log_cur1, self.slots1 = [], [], [], [], []
         self.off_shape = {}          # (lane, shapes) -> a captured body for a minibatch of another size (the ragged last one)

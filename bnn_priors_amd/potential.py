@@ -78,15 +78,16 @@ class Potential:
     # ------------------------------------------------------------------ full-data gradient
     graph_exact = False     # set by the runner (``use_graph``): capture the exact pass's batch body
 
-    def _make_exact_accumulator(self, x, y):
+    def _make_exact_accumulator(self, x, y, n_full=None):
         """graph-captured accumulation: L launches, no read-back (graphed.GraphedAccumulate) -- for the launch-bound
         convolutional nets on EXACT_LANES streams at once (graphed.ConcurrentAccumulate)"""
         from . import bn as _bn, graphed
         from .models import nets
-        if ((graphed.EXACT_LANES > 1 or graphed.EXACT_GROUP > 1)
+        if ((graphed.EXACT_LANES > 1 or graphed.EXACT_GROUP != 1)
                 and any(isinstance(m, nets.Conv2d) for m in self.model.modules())):
             try:
-                return graphed.ConcurrentAccumulate(self, self.opt, x, y, lanes=max(1, graphed.EXACT_LANES))
+                return graphed.ConcurrentAccumulate(self, self.opt, x, y, lanes=max(1, graphed.EXACT_LANES),
+                                                    n_full=n_full)
             except _bn.LogModeUnsupported:
                 pass
         return graphed.GraphedAccumulate(self, self.opt, x, y)
@@ -120,7 +121,8 @@ class Potential:
             # else from the first minibatch (never peeked at beyond what is consumed: iterating the loader draws from its RNG)
             first = batches.example() if hasattr(batches, "example") else None
             if first is not None:
-                acc = self._exact_acc = self._make_exact_accumulator(*first)
+                n_full = batches.n_full_batches() if hasattr(batches, "n_full_batches") else None
+                acc = self._exact_acc = self._make_exact_accumulator(*first, n_full=n_full)
                 acc.begin()
             else:
                 batches = iter(batches)
