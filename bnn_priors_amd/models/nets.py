@@ -276,6 +276,10 @@ class _BNTrunk(nn.Sequential):
         out, mods, i = x, list(self), 0
         # (log mode: the caller advances the counters afterwards)
         counters = self._flat_counters() if (self.training and not _bn.log_active()) else None
+        if counters is not None and counters.numel() > 256:      # (the head's launch advances up to 256 counters)
+            with torch.no_grad():
+                counters.add_(1)
+            counters = None
         counted = counters is None
         while i < len(mods):
             m = mods[i]
