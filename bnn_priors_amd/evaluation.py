@@ -44,7 +44,12 @@ class _NotBatchable(Exception):
     "the grouped (vmap) evaluation cannot run this model / these samples: evaluate sample by sample instead"
 
 
-BATCHED = os.environ.get("SGMCMC_EVAL_BATCHED", "1") != "0"   # stack the samples: ONE grouped forward per test batch
+# Stack the samples and run ONE grouped (vmap) forward per test batch on the library's batched layers.  OFF by default
+# since round 4: once the test set is sliced instead of iterated (``_resident_tensors``) the sample-by-sample pass on
+# this package's kernels -- a captured forward per 1,024 rows, ``load_state_dict`` per sample -- is 3-4x faster for all
+# three BASELINE nets (10 samples x 10,000 rows, tools/eval_probe.py: googleresnet 141 vs 427 ms, convnet 24 vs 71,
+# densenet 15 vs 58), needs no MIOpen kernel search (1.4-5 s on first use) and gives the per-epoch evaluation's bits.
+BATCHED = os.environ.get("SGMCMC_EVAL_BATCHED", "0") == "1"
 SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation memory at E_group * batch images
 
 
@@ -126,10 +131,43 @@ EVAL_GRAPH = os.environ.get("SGMCMC_EVAL_GRAPH", "1") != "0"
 EVAL_ROWS = int(os.environ.get("SGMCMC_EVAL_ROWS", "1024"))
 
 
+def _resident_tensors(dataloader):
+    """(x, y) when the loader is a plain in-order pass over a TensorDataset-like set (``.tensors``, SequentialSampler,
+    default collation, no workers): its batches are consecutive slices of those tensors, so the evaluation can slice them
+    itself instead of iterating the DataLoader -- which indexes the set item by item and stacks 128 views per batch,
+    ~0.3 ms of host time each: 24 of the 28 ms a per-epoch evaluation of 10,000 rows took"""
+    ds = getattr(dataloader, "dataset", None)
+    t = getattr(ds, "tensors", None)
+    if (t is None or len(t) != 2 or getattr(ds, "augment", None) is not None
+            or not isinstance(getattr(dataloader, "sampler", None), torch.utils.data.SequentialSampler)
+            or dataloader.batch_size is None or dataloader.num_workers != 0
+            or dataloader.collate_fn is not torch.utils.data.default_collate):
+        return None
+    n = len(ds)
+    if dataloader.drop_last:
+        n -= n % dataloader.batch_size
+    return t[0][:n], t[1][:n]
+
+
 def _row_groups(dataloader, device, rows):
     "the loader's batches, consecutive ones concatenated up to ``rows`` rows (order kept; the last group is what is left)"
     if rows <= 0:
         yield from dataloader
+        return
+    res = _resident_tensors(dataloader)
+    if res is not None:
+        # the same groups: whole batches up to ``rows`` rows each, as slices of the set (moved once if it lives on the host)
+        bs = dataloader.batch_size
+        per = max(bs, rows // bs * bs)
+        key = (res[0].data_ptr(), res[1].data_ptr(), str(device))
+        cached = _resident_cache.get(id(dataloader))
+        if cached is None or cached[0] != key:
+            cached = _resident_cache[id(dataloader)] = (key, res[0].to(device), res[1].to(device))
+            if len(_resident_cache) > 8:
+                _resident_cache.pop(next(iter(_resident_cache)))
+        x, y = cached[1], cached[2]
+        for i in range(0, x.shape[0], per):
+            yield x[i:i + per], y[i:i + per]
         return
     xs, ys, have = [], [], 0
     for bx, by in dataloader:
@@ -141,6 +179,9 @@ def _row_groups(dataloader, device, rows):
         have += len(bx)
     if xs:
         yield (torch.cat(xs), torch.cat(ys)) if len(xs) > 1 else (xs[0], ys[0])
+
+
+_resident_cache = {}        # id(loader) -> (key, x on the device, y on the device): host-resident test sets are moved once
 
 
 class _GraphedLogits:

@@ -54,10 +54,11 @@ def test_grouped_evaluation_on_gpu_matches_the_loop_and_is_taken(name, monkeypat
     used = []
     real = ev._predictive_tables_batched
     monkeypatch.setattr(ev, "_predictive_tables_batched", lambda *a: (used.append(1), real(*a))[1])
+    want = ev.evaluate_model(net, loader, samples)          # the default: this repo's kernels, sample by sample
+    assert not used and not ev.BATCHED                      # (the library's batched layers are not entered by default)
+    monkeypatch.setattr(ev, "BATCHED", True)
     got = ev.evaluate_model(net, loader, samples)
-    assert used                                             # the grouped path ran (and did not fall back)
-    monkeypatch.setattr(ev, "BATCHED", False)
-    want = ev.evaluate_model(net, loader, samples)          # this repo's kernels, sample by sample
+    assert used                                             # the grouped path ran when asked for (and did not fall back)
     for k in want:
         assert got[k] == pytest.approx(want[k], rel=2e-4, abs=2e-4), k
     from bnn_priors_amd import conv
@@ -68,7 +69,11 @@ def test_row_groups_concatenate_consecutive_batches_in_order():
     x = torch.arange(100, dtype=torch.float32).view(100, 1)
     y = torch.arange(100)
     loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=16)
-    groups = list(ev._row_groups(loader, "cpu", 40))                  # 16 + 16 | 16 + 16 | 16 + 16 + 4
+    groups = list(ev._row_groups(loader, "cpu", 40))                  # an in-order TensorDataset loader: sliced, not iterated
+    assert [len(gx) for gx, _ in groups] == [32, 32, 32, 4]           # whole batches per group; the ragged batch on its own
+    assert torch.equal(torch.cat([gx for gx, _ in groups]), x) and torch.equal(torch.cat([gy for _, gy in groups]), y)
+    shuffled = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=16, sampler=list(range(100)))
+    groups = list(ev._row_groups(shuffled, "cpu", 40))                # any other loader is iterated: 16 + 16 | 16 + 16 | 16 + 16 + 4
     assert [len(gx) for gx, _ in groups] == [32, 32, 36]
     assert torch.equal(torch.cat([gx for gx, _ in groups]), x) and torch.equal(torch.cat([gy for _, gy in groups]), y)
     assert [len(gx) for gx, _ in ev._row_groups(loader, "cpu", 0)] == [16] * 6 + [4]      # 0: the loader's own batches
