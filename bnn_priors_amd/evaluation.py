@@ -157,6 +157,10 @@ def _row_groups(dataloader, device, rows):
     res = _resident_tensors(dataloader)
     if res is not None:
         # the same groups: whole batches up to ``rows`` rows each, as slices of the set (moved once if it lives on the host)
+        # DataLoader.__iter__ draws a worker base seed from the (global) generator before anything else
+        # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__): a run that iterates the test loader -- the
+        # reference's evaluate_model -- consumes it, and the plain runners seed their next shuffle from the same stream
+        torch.empty((), dtype=torch.int64).random_(generator=dataloader.generator)
         bs = dataloader.batch_size
         per = max(bs, rows // bs * bs)
         key = (res[0].data_ptr(), res[1].data_ptr(), str(device))
