@@ -531,6 +531,9 @@ class ConcurrentAccumulate:
                     for j in range(G):
                         target["dst"] = lambda rows, j=j: lane.slot(j) if rows == lane.rows else None
                         x, y = next(it)
+                        if not lane.matches(x, y):      # (the contract of n_full_batches: the FIRST n_full ones are full)
+                            raise RuntimeError("a batch source that announces its full-size minibatches must yield them "
+                                               f"first: got {tuple(x.shape)} inside a group of {lane.shape[0]}")
                         if not lane.owns(x, y, j):
                             xs, ys = lane.slot(j)
                             stage_batch(xs, x, ys, y)

@@ -180,7 +180,8 @@ class _BatchSource:
             self._provider = old
 
     def n_full_batches(self):
-        "how many of this source's minibatches have the full batch size (None: unknown)"
+        """how many of this source's minibatches have the full batch size -- and come FIRST, in every traversal (the
+        ragged one, if any, is the last: what a batch sampler over a map-style set yields); None: unknown"""
         if not self.fast:
             return None
         return len(self.dl.dataset) // self.dl.batch_size
