@@ -230,6 +230,16 @@ class _BatchSource:
         so that a kernel can gather them itself; falls back to tensors when not ``fast``"""
         return self._iterate(True)
 
+    def _stage_into(self, idx, draw, xd, yd):
+        "rows ``idx`` (+ labels) gathered into (xd, yd) by one launch (LazyBatch.stage); False: not possible, gather as usual"
+        if not self.x.is_cuda:
+            return False
+        lb = LazyBatch(self, idx, draw)
+        if not lb.stageable(xd, yd):
+            return False
+        lb.stage(xd, yd, [], None, None, torch.cuda.current_stream(self.x.device).cuda_stream)
+        return True
+
     def lazy_batches(self):
         """same minibatches, same RNG consumption, but as ``LazyBatch`` objects (x still in the data set): the consumer
         gathers them where it wants them (``LazyBatch.stage``); falls back to tensors when not ``fast``"""
@@ -258,6 +268,9 @@ class _BatchSource:
                     yield LazyBatch(self, idx, draw), None
                     continue
                 xd, yd = self._dst(idx.numel())
+                if xd is not None and self._stage_into(idx, draw, xd, yd):
+                    yield xd, yd                    # (images + labels gathered into the consumer's buffers by ONE launch)
+                    continue
                 yield (self.augment.gather(self.x, idx, draw, out=xd),
                        self.y.index_select(0, idx) if yd is None else torch.index_select(self.y, 0, idx, out=yd))
             self._exhausted(gen)
@@ -288,6 +301,8 @@ class _BatchSource:
                 idx = perm[i:i + bs]
                 if xd is None:
                     yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+                elif self._stage_into(idx, None, xd, yd):
+                    yield xd, yd
                 else:
                     yield torch.index_select(self.x, 0, idx, out=xd), torch.index_select(self.y, 0, idx, out=yd)
         self._exhausted(gen)
