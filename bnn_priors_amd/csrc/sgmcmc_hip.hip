@@ -1183,6 +1183,9 @@ int launch_step(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sgmcmc_
     return (int)hipErrorInvalidValue;
   if (A->kind < SGMCMC_VERLET || A->kind > SGMCMC_SGLD) return (int)hipErrorInvalidValue;
   if (L->chunk_elems != SGMCMC_CHUNK && L->chunk_elems != SGMCMC_CHUNK_SMALL) return (int)hipErrorInvalidValue;
+  // the graph-replay kernels request their chunk's m and v before they know the transition's flags: both arenas have to
+  // exist (padded to whole chunks) on every path, SGLD without momentum and final steps included
+  if (Ad && (!L->m || !L->v)) return (int)hipErrorInvalidValue;
   // the in-flight prior exists for the graph-replay kernel on float32 arenas only
   if ((A->flags & SGMCMC_INLINE_PRIOR) && (!Ad || G || L->dtype != SGMCMC_F32)) return (int)hipErrorInvalidValue;
   // ... and, like the gradient-assembling kernels, carries the lean prior code only

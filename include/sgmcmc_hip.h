@@ -181,8 +181,10 @@ int sgmcmc_step_timed(const sgmcmc_layout* L, const sgmcmc_step_args* A, void* s
 /* As sgmcmc_step, but the kernels read the transition's scalars from DEVICE memory
  * (*A_dev, same struct) when they run.  Launch geometry and kernel selection (kind, dtype,
  * seg/chunk ranges, SGMCMC_UNALIGNED, SGMCMC_NO_MOMENTUM) are taken from *A_host and must not
- * differ in *A_dev.  This is what makes the launch capturable in a hipGraph that is replayed
- * with a different learning rate / draw counter / flags every step. */
+ * differ in *A_dev (the kernels take chunk_begin from *A_host and request their chunk's m and v before *A_dev has
+ * arrived: L->m and L->v must be non-NULL and padded to whole chunks whatever the flags; NULL: hipErrorInvalidValue).
+ * This is what makes the launch capturable in a hipGraph that is replayed with a different learning rate / draw
+ * counter / flags every step. */
 int sgmcmc_step_indirect(const sgmcmc_layout* L, const sgmcmc_step_args* A_host,
                          const sgmcmc_step_args* A_dev, void* stream);
 
