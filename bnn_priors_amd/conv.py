@@ -56,6 +56,16 @@ DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
 PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "0") == "1"
 
 
+# ... and, per trunk stage, for the BACKWARD launch alone (forward on the default kernels, so the BatchNorm that follows
+# reads the default statistics slices): "32x16,64x8" style list of (channels x side) -- an A/B switch of round 4
+PERSISTENT_BWD = {tuple(int(v) for v in item.split("x"))
+                  for item in os.environ.get("SGMCMC_CONV_PERSISTENT_BWD", "").split(",") if item}
+
+
+def persistent_bwd(c, hw):
+    return PERSISTENT or (c, hw) in PERSISTENT_BWD
+
+
 @contextlib.contextmanager
 def persistent(on=True):
     "scope in which the trunk's 3x3 convolutions (forward and both gradients) run on the persistent kernels"
@@ -174,7 +184,7 @@ def deferring(owner=None):
     _fx_reset(owner)
     _frag_valid.clear()
     _pending.clear()                # leftovers of a pass that raised before its final callback
-    if PERSISTENT and owner is not None:
+    if (PERSISTENT or PERSISTENT_BWD) and owner is not None:
         known = [w for w in (r() for r in _owner_weights.get(id(owner), ())) if w is not None and w.is_cuda]
         if known:
             _prepare(known)
@@ -331,7 +341,7 @@ def _both_grads(x, w, dy, defer, sums_for=None):
     "``sums_for`` = (y_bn, out_bn, saved_bn) of the BatchNorm + ReLU that produced x: its backward sums ride along"
     lib = _hip.lib()
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
-    if PERSISTENT and not (defer and SIDE_STREAM):
+    if persistent_bwd(c, hw) and not (defer and SIDE_STREAM):
         dx, dw, partial, n_part = frag_backward(lib, x, w, dy, defer, sums_for=sums_for)
         if partial is not None:
             _bnlink.tag_gradient(dx, partial, n_part)

@@ -227,7 +227,7 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
     ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward whose incoming gradient
     dx is -> (dx, dw, partial or None, n_partials)"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
-    if _conv.PERSISTENT and not (_conv.SIDE_STREAM and _conv._may_defer(w)):
+    if _conv.persistent_bwd(c, hw) and not (_conv.SIDE_STREAM and _conv._may_defer(w)):
         defer = _conv._may_defer(w)
         if defer:      # summed with the pass's other slabs by ONE launch at its end
             torch.autograd.Variable._execution_engine.queue_callback(_conv._flush_pending)
