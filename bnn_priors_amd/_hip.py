@@ -91,7 +91,8 @@ class ReduceJob(ctypes.Structure):
 class ConvBwdEpilogue(ctypes.Structure):
     "sgmcmc_conv_bwd_epilogue"
     _fields_ = ([(n, ctypes.c_void_p) for n in ("e_dout", "e_out", "s_y", "s_out", "s_mean", "s_invstd", "s_partial")]
-                + [("group_imgs", ctypes.c_int32), ("wrw_mult", ctypes.c_int32)])
+                + [("group_imgs", ctypes.c_int32), ("wrw_mult", ctypes.c_int32), ("mask_dx", ctypes.c_int32),
+                   ("reserved", ctypes.c_int32)])
 
 
 class BnResidualSums(ctypes.Structure):

@@ -250,16 +250,21 @@ class _BNTrain(torch.autograd.Function):
                                              stats[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, plane, G, st)
                 if err:
                     _hip.check(err, "sgmcmc_bn_bwd_sums")
-                up = (sums, n_sums.value)
+                up = (sums, n_sums.value, False)
+            # dy stored as dy * [y > 0] by the launch that produced it (bnlink.PREMASK): no mask to apply, y is not
+            # read, and the residual's gradient IS dy
+            masked = ctx.relu and up[2]
+            if masked and want_res:
+                dres = dy
             R = None
             if rsums:
                 r_part = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane, G), dtype=torch.float64, device=x.device)
                 R = _hip.BnResidualSums(y=res_y.data_ptr(), mean=res_saved[0].data_ptr(),
                                         invstd=res_saved[1].data_ptr(), partial=r_part.data_ptr())
-            err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), _ptr(y), x.data_ptr(), weight.data_ptr(), stats[0].data_ptr(),
-                                       stats[1].data_ptr(), int(ctx.relu), n, c, plane, up[0].data_ptr(), up[1],
-                                       dx.data_ptr(), 0 if dres is dy else _ptr(dres), dgb.data_ptr(),
-                                       None if R is None else ctypes.byref(R), G, st)
+            err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), 0 if masked else _ptr(y), x.data_ptr(), weight.data_ptr(),
+                                       stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.relu and not masked), n, c, plane,
+                                       up[0].data_ptr(), up[1], dx.data_ptr(), 0 if dres is dy else _ptr(dres),
+                                       dgb.data_ptr(), None if R is None else ctypes.byref(R), G, st)
             if err:
                 _hip.check(err, "sgmcmc_bn_bwd_dx")
             if rsums:
@@ -346,15 +351,18 @@ class _BNTrainDual(torch.autograd.Function):
                                          saved[1].data_ptr(), sums.data_ptr(), ctypes.byref(n_sums), n, c, plane, G, st)
             if err:
                 _hip.check(err, "sgmcmc_bn_bwd_sums")
-            up = (sums, n_sums.value)
-        dx, dz, dr = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            up = (sums, n_sums.value, False)
+        masked = up[2]         # dy stored as dy * [y > 0] by its producer (bnlink.PREMASK): dz IS dy
+        dx, dr = torch.empty_like(x), torch.empty_like(x)
+        dz = dy if masked else torch.empty_like(x)
         dgb = torch.empty((2, G, 2, c), dtype=torch.float32, device=x.device)
         r_part = torch.empty(lib.sgmcmc_bn_scratch_doubles(n, c, plane, G), dtype=torch.float64, device=x.device)
         R = _hip.BnResidualSums(y=r.data_ptr(), mean=r_saved[0].data_ptr(), invstd=r_saved[1].data_ptr(),
                                 partial=r_part.data_ptr())
-        err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), y.data_ptr(), x.data_ptr(), weight.data_ptr(), saved[0].data_ptr(),
-                                   saved[1].data_ptr(), 1, n, c, plane, up[0].data_ptr(), up[1], dx.data_ptr(),
-                                   dz.data_ptr(), dgb[0].data_ptr(), ctypes.byref(R), G, st)
+        err = lib.sgmcmc_bn_bwd_dx(dy.data_ptr(), 0 if masked else y.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                                   saved[0].data_ptr(), saved[1].data_ptr(), 0 if masked else 1, n, c, plane,
+                                   up[0].data_ptr(), up[1], dx.data_ptr(), 0 if masked else dz.data_ptr(),
+                                   dgb[0].data_ptr(), ctypes.byref(R), G, st)
         if err:
             _hip.check(err, "sgmcmc_bn_bwd_dx")
         err = lib.sgmcmc_bn_bwd_dx(dz.data_ptr(), 0, r.data_ptr(), r_weight.data_ptr(), r_saved[0].data_ptr(),

@@ -17,6 +17,15 @@ models/google_resnet.py:34-43 (inference.py:215-223)."""
 import os
 
 ENABLED = os.environ.get("SGMCMC_BN_EPILOGUE_SUMS", "1") != "0"
+# Round 4: a launch that leaves the sums also STORES the gradient masked, dz = dx * [out > 0] (``mask_dx`` of
+# sgmcmc_conv_bwd_epilogue: it holds the mask for the sums anyway).  The gradient of a BatchNorm + ReLU output has two
+# kinds of consumers -- the BatchNorm's dx launch and the shortcut add of the residual block before -- and both form
+# exactly dz from it, so with the tag's ``masked`` flag neither reads ``out`` again (a quarter of the dx launch's
+# traffic; same bits).  Where the tag is lost (a gradient autograd accumulated) the consumers mask as before, which is
+# correct for a masked operand too: (dz + other) * [out > 0] = (dx + other) * [out > 0].  What changes: the gradient
+# autograd holds for such an activation is dz, not dx -- they differ only where the activation is exactly 0, where
+# the ReLU's own backward zeroes it.  SGMCMC_PREMASK=0 stores dx as before.
+PREMASK = ENABLED and os.environ.get("SGMCMC_PREMASK", "1") != "0"
 STATS = {"upstream": 0, "own": 0}        # BatchNorm backward passes that found their sums / launched their own
 
 
@@ -49,16 +58,17 @@ def linear_source_of(r):
     return src
 
 
-def tag_gradient(dx, partial, n_partials):
-    dx._sgmcmc_bn_sums = (partial, n_partials, dx._version, dx.data_ptr())
+def tag_gradient(dx, partial, n_partials, masked=False):
+    "``masked``: dx was stored as dz = dx * [out > 0] (PREMASK)"
+    dx._sgmcmc_bn_sums = (partial, n_partials, dx._version, dx.data_ptr(), bool(masked))
     return dx
 
 
 def sums_of(dout):
-    "(partial, n_partials) left by the launch that produced dout, or None"
+    "(partial, n_partials, masked) left by the launch that produced dout, or None"
     tok = getattr(dout, "_sgmcmc_bn_sums", None) if ENABLED else None
     if tok is None or tok[2] != dout._version or tok[3] != dout.data_ptr() or not dout.is_contiguous():
         STATS["own"] += 1
         return None
     STATS["upstream"] += 1
-    return tok[0], tok[1]
+    return tok[0], tok[1], tok[4]

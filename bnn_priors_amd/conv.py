@@ -299,8 +299,8 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
     dx = torch.empty_like(x)
     dw = torch.empty((c, c, 3, 3), dtype=torch.float32, device=x.device)
     E = _hip.ConvBwdEpilogue()
-    if add is not None:
-        E.e_dout, E.e_out = add[0].data_ptr(), add[1].data_ptr()
+    if add is not None:      # (e_out None: e_dout is masked already -- bnlink.PREMASK)
+        E.e_dout, E.e_out = add[0].data_ptr(), 0 if add[1] is None else add[1].data_ptr()
     partial, n_part = None, lib.sgmcmc_conv3x3_frag_stat_slices(n, c, hw)
     if sums_for is not None:
         y_bn, out_bn, saved_bn = sums_for
@@ -309,6 +309,7 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
                                                 saved_bn[1].data_ptr())
         E.s_partial = partial.data_ptr()
         E.group_imgs = _group_imgs(n)
+        E.mask_dx = int(_bnlink.PREMASK)         # dx leaves as dx * [out_bn > 0]: what its consumers form from it
     slabs = ctypes.c_int(0)
     err = lib.sgmcmc_conv3x3_frag_bwd(x.data_ptr(), frags(w)[1].data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
                                       0 if defer else dw.data_ptr(), scratch.data_ptr(), n, c, hw,
@@ -344,7 +345,7 @@ def _both_grads(x, w, dy, defer, sums_for=None):
     if persistent_bwd(c, hw) and not (defer and SIDE_STREAM):
         dx, dw, partial, n_part = frag_backward(lib, x, w, dy, defer, sums_for=sums_for)
         if partial is not None:
-            _bnlink.tag_gradient(dx, partial, n_part)
+            _bnlink.tag_gradient(dx, partial, n_part, _bnlink.PREMASK)
         return dx, dw
     scratch = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
@@ -357,10 +358,11 @@ def _both_grads(x, w, dy, defer, sums_for=None):
             n_part = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
             partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
             E = _hip.ConvBwdEpilogue(s_y=y_bn.data_ptr(), s_out=out_bn.data_ptr(), s_mean=saved_bn[0].data_ptr(),
-                                     s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr())
+                                     s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr(),
+                                     mask_dx=int(_bnlink.PREMASK))
         split_backward(lib, x, w, dy, dx, E, scratch, slabs)
         if partial is not None:
-            _bnlink.tag_gradient(dx, partial, n_part)
+            _bnlink.tag_gradient(dx, partial, n_part, _bnlink.PREMASK)
         _pending.append((scratch, dw, slabs.value, 9))
         return dx, dw.view(dw.shape)
     if sums_for is None:
@@ -372,13 +374,13 @@ def _both_grads(x, w, dy, defer, sums_for=None):
         partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
         E = _hip.ConvBwdEpilogue(s_y=y_bn.data_ptr(), s_out=out_bn.data_ptr(), s_mean=saved_bn[0].data_ptr(),
                                  s_invstd=saved_bn[1].data_ptr(), s_partial=partial.data_ptr(),
-                                 group_imgs=_group_imgs(n))
+                                 group_imgs=_group_imgs(n), mask_dx=int(_bnlink.PREMASK))
         from . import bn as _bn
         E.wrw_mult = WRW_GROUP_MULT and _bn.groups()
         err = lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
                                         dw.data_ptr(), scratch.data_ptr(), n, c, hw,
                                         ctypes.byref(slabs) if defer else None, _stream())
-        _bnlink.tag_gradient(dx, partial, n_part)
+        _bnlink.tag_gradient(dx, partial, n_part, _bnlink.PREMASK)
     if err:
         _hip.check(err, "sgmcmc_conv3x3_bwd")
     if defer:
@@ -555,12 +557,12 @@ class _ConvDown(torch.autograd.Function):
             partial = torch.empty((c, n_part, 2), dtype=torch.float64, device=x.device)
             E = _hip.ConvBwdEpilogue(s_y=src_y.data_ptr(), s_out=x.data_ptr(), s_mean=src_saved[0].data_ptr(),
                                      s_invstd=src_saved[1].data_ptr(), s_partial=partial.data_ptr(),
-                                     group_imgs=_group_imgs(n))
+                                     group_imgs=_group_imgs(n), mask_dx=int(_bnlink.PREMASK))
             err = lib.sgmcmc_conv_down_bwd_ex(x.data_ptr(), w_main.data_ptr(), w_short.data_ptr(), dym.data_ptr(),
                                               dys.data_ptr(), dx.data_ptr(), ctypes.byref(E), dwm.data_ptr(),
                                               dws.data_ptr(), scratch.data_ptr(), n, c, hw,
                                               ctypes.byref(slabs) if defer else None, _stream())
-            _bnlink.tag_gradient(dx, partial, n_part)
+            _bnlink.tag_gradient(dx, partial, n_part, _bnlink.PREMASK)
         if err:
             _hip.check(err, "sgmcmc_conv_down_bwd")
         if defer:   # scratch = [slabs][dwm.numel()] then [slabs][dws.numel()]

@@ -198,13 +198,14 @@ def _conv_bn_bwd(lib, x, w, y, out, dout, saved, g, dgb, e_dout, e_out, s):
     return dx, _reduce_or_defer(lib, w, part, slabs.value, s)
 
 
-def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s, G=1):
-    "dy of out = relu(bn(y) [+ r]) given dout and the channel sums' partials; dgb [G][2][C] <- the groups' dgamma, dbeta"
+def _bn_dx(lib, dout, out, y, saved, g, dgb, partial, n_partials, s, G=1, masked=False):
+    """dy of out = relu(bn(y) [+ r]) given dout and the channel sums' partials; dgb [G][2][C] <- the groups' dgamma, dbeta;
+    ``masked``: dout arrives as dout * [out > 0] (bnlink.PREMASK) and ``out`` is not read"""
     n, c, hw = y.shape[0], y.shape[1], y.shape[2]
     dy = torch.empty_like(y)
-    err = lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), g.data_ptr(), saved[0].data_ptr(),
-                               saved[1].data_ptr(), 1, n, c, hw * hw, partial.data_ptr(), n_partials, dy.data_ptr(), 0,
-                               dgb.data_ptr(), None, G, s)
+    err = lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), 0 if masked else out.data_ptr(), y.data_ptr(), g.data_ptr(),
+                               saved[0].data_ptr(), saved[1].data_ptr(), 0 if masked else 1, n, c, hw * hw,
+                               partial.data_ptr(), n_partials, dy.data_ptr(), 0, dgb.data_ptr(), None, G, s)
     if err:
         _hip.check(err, "sgmcmc_bn_bwd_dx")
     return dy
@@ -223,9 +224,10 @@ def _bn_sums(lib, dout, out, y, saved, s, G=1):
 
 
 def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
-    """both gradients of y = conv3x3(x, w) given dy; ``add`` = (e_dout, e_out): dx += e_dout * [e_out > 0];
-    ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward whose incoming gradient
-    dx is -> (dx, dw, partial or None, n_partials)"""
+    """both gradients of y = conv3x3(x, w) given dy; ``add`` = (e_dout, e_out): dx += e_dout * [e_out > 0] (e_out None:
+    e_dout is masked already); ``sums_for`` = (y_bn, out_bn, saved_bn): also the partial sums of the BatchNorm backward
+    whose incoming gradient dx is, and (bnlink.PREMASK) dx is stored as dx * [out_bn > 0]
+    -> (dx, dw, partial or None, n_partials)"""
     n, c, hw = x.shape[0], x.shape[1], x.shape[2]
     if _conv.persistent_bwd(c, hw) and not (_conv.SIDE_STREAM and _conv._may_defer(w)):
         defer = _conv._may_defer(w)
@@ -237,7 +239,7 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
     E = _hip.ConvBwdEpilogue()
     E.wrw_mult = _conv.WRW_GROUP_MULT and G       # (several minibatches: the slab count of one)
     if add is not None:
-        E.e_dout, E.e_out = add[0].data_ptr(), add[1].data_ptr()
+        E.e_dout, E.e_out = add[0].data_ptr(), _p(add[1])
     partial, n_partials = None, lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
     if sums_for is not None:
         y_bn, out_bn, saved_bn = sums_for
@@ -245,6 +247,7 @@ def _conv_bwd_ex(lib, x, w, dy, s, add=None, sums_for=None, G=1):
         E.s_y, E.s_out, E.s_mean, E.s_invstd = y_bn.data_ptr(), out_bn.data_ptr(), saved_bn[0].data_ptr(), saved_bn[1].data_ptr()
         E.s_partial = partial.data_ptr()
         E.group_imgs = n // G if G > 1 else 0
+        E.mask_dx = int(_bnlink.PREMASK)
     slabs = ctypes.c_int(0)
     if _conv.SIDE_STREAM and _conv._may_defer(w):
         # the weight-gradient slabs leave the critical path: side stream, joined before the pass's slab reduction
@@ -300,15 +303,16 @@ class _Block(torch.autograd.Function):
         dgb = torch.empty((2, G, 2, x.shape[1]), dtype=torch.float32, device=x.device)     # [layer][group][gamma, beta][C]
         if EPILOGUE_SUMS:
             # bn2's sums: left by the launch that produced dout (the next block's conv1 gradient), else a launch here
-            sums2, n2 = up if up is not None else _bn_sums(lib, dout, out, y2, saved2, s, G)
-            dy2 = _bn_dx(lib, dout, out, y2, saved2, g2, dgb[1], sums2, n2, s, G)
+            # (masked: the launch that produced dout stored it as dout * [out > 0] -- bnlink.PREMASK)
+            sums2, n2, masked = up if up is not None else (*_bn_sums(lib, dout, out, y2, saved2, s, G), False)
+            dy2 = _bn_dx(lib, dout, out, y2, saved2, g2, dgb[1], sums2, n2, s, G, masked)
             dh, dw2, sums1, n1 = _conv_bwd_ex(lib, h, w2, dy2, s, sums_for=(y1, h, saved1), G=G)
-            dy1 = _bn_dx(lib, dh, h, y1, saved1, g1, dgb[0], sums1, n1, s, G)
+            dy1 = _bn_dx(lib, dh, h, y1, saved1, g1, dgb[0], sums1, n1, s, G, _bnlink.PREMASK)
             # ... and this block's input came out of a BatchNorm + ReLU too: its sums ride in conv1's gradient launch
-            dx, dw1, sums0, n0 = _conv_bwd_ex(lib, x, w1, dy1, s, add=(dout, out),
+            dx, dw1, sums0, n0 = _conv_bwd_ex(lib, x, w1, dy1, s, add=(dout, None if masked else out),
                                               sums_for=None if src_y is None else (src_y, x, src_saved), G=G)
             if sums0 is not None:
-                _bnlink.tag_gradient(dx, sums0, n0)
+                _bnlink.tag_gradient(dx, sums0, n0, _bnlink.PREMASK)
         elif (x.shape[1], x.shape[2]) in FUSED_BN_BWD:
             dh, dw2 = _conv_bn_bwd(lib, h, w2, y2, out, dout, saved2, g2, dgb[1, 0], None, None, s)
             # the shortcut carries dz2 = dout * [out > 0] back to x: added in conv1's data-gradient epilogue

@@ -407,7 +407,7 @@ int sgmcmc_conv3x3_bwd(const float* x, const float* w, const float* dy, float* d
 int sgmcmc_conv3x3_bwd_add(const float* x, const float* w, const float* dy, float* dx, const float* e_dout,
                            const float* e_out, float* dw, float* scratch, int n_img, int channels, int hw,
                            int* deferred_slabs, void* stream);
-/* The general form: the data gradient's epilogue may add the shortcut's gradient (e_dout / e_out, both or neither)
+/* The general form: the data gradient's epilogue may add the shortcut's gradient (e_dout masked by [e_out > 0]; e_out NULL: e_dout as it is -- see mask_dx)
  * and / or leave the partial sums of the BatchNorm backward that CONSUMES dx as its incoming gradient (s_*: that
  * BatchNorm's input y, its post-ReLU output, its saved mean / invstd): s_partial[(c * S + slice) * 2 + {0,1}] =
  * sum dz, sum dz * xhat over the slice, dz = dx * [s_out > 0], xhat = (s_y - mean_c) * invstd_c, S =
@@ -424,6 +424,12 @@ typedef struct {
                        * (image, band) items, i.e. *deferred_slabs shrinks by that factor -- for launches that carry
                        * several minibatches (the slab count of ONE minibatch, each slab the sum over more images;
                        * another summation grouping than wrw_mult = 1: equal to rounding); 0 / 1: the default */
+  int32_t mask_dx;    /* with s_partial: dx is STORED as dz = dx * [s_out > 0].  Everything that consumes the gradient of a
+                       * BatchNorm + ReLU output forms exactly that from it (the BatchNorm's own backward; the shortcut add
+                       * of the residual block before), so neither has to read s_out again: feed such a dx to
+                       * sgmcmc_bn_bwd_dx with relu = 0 (y unused) and as e_dout with e_out = NULL (added as it is).
+                       * Same bits as masking at the consumers. */
+  int32_t reserved;
 } sgmcmc_conv_bwd_epilogue;
 int sgmcmc_conv3x3_bwd_ex(const float* x, const float* w, const float* dy, float* dx,
                           const sgmcmc_conv_bwd_epilogue* epi, float* dw, float* scratch, int n_img, int channels,
@@ -620,8 +626,10 @@ int sgmcmc_bn_bwd_sums(const float* dout, const float* out, const float* y, cons
 /* The second launch of sgmcmc_bn_train_bwd alone, for partial sums that already exist: `partial` =
  * [channels][n_partials][2] doubles (sum dz, sum dz * xhat per slice) from sgmcmc_bn_bwd_sums or from the epilogue of
  * the convolution gradient that produced dy (sgmcmc_conv3x3_bwd_ex).
- * rs (may be NULL; needs relu and dresidual): the residual is itself the output of a BatchNorm WITHOUT ReLU (the
- * down-sampling block's shortcut, models/google_resnet.py:77-90) whose incoming gradient is dresidual; the launch
+ * rs (may be NULL): the residual is itself the output of a BatchNorm WITHOUT ReLU (the down-sampling block's shortcut,
+ * models/google_resnet.py:77-90) whose incoming gradient is dresidual = dz -- with relu: formed here and stored
+ * (dresidual required); with relu = 0: dy arrives masked already (sgmcmc_conv_bwd_epilogue.mask_dx), the residual's
+ * gradient IS dy and dresidual must be NULL; the launch
  * also leaves that BatchNorm's backward sums in rs->partial, [channels][sgmcmc_bn_scratch_doubles(...) / (2
  * channels)][2] doubles (the slices of this launch's own geometry); rs->mean / rs->invstd: [G][channels]. */
 typedef struct {

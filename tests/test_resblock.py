@@ -201,6 +201,50 @@ def test_batchnorm_backward_sums_ride_in_the_upstream_convolution_gradient(monke
     assert bnlink.sums_of(t) is None
 
 
+@pytest.mark.parametrize("route", ["blocks", "layered", "persistent"])
+def test_gradients_stored_masked_by_their_producers_change_no_bit(route, monkeypatch):
+    """bnlink.PREMASK: a launch that leaves a BatchNorm's backward sums stores its data gradient as dx * [out > 0]; the
+    BatchNorm's dx launch then runs without the ReLU mask (it does not read `out`) and the shortcut add takes the
+    gradient as it is.  Every parameter gradient of googleresnet keeps its bits -- fused residual blocks, the
+    layer-by-layer operators (conv3x3 / conv_down / bn_train / bn_train_dual) and the persistent convolutions."""
+    from bnn_priors_amd import bnlink, models, resblock
+    torch.manual_seed(1)
+    x = torch.randn(24, 3, 32, 32).cuda()
+    y = torch.randint(0, 10, (24,)).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    models.he_initialize(net)
+    net.train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    if route == "layered":
+        monkeypatch.setattr(resblock, "ENABLED", False)
+
+    def grads():
+        net.load_state_dict(state)
+        for p in net.parameters():
+            p.grad = None
+        if route == "persistent":
+            with conv.persistent():
+                loss = torch.nn.functional.cross_entropy(net.net(x), y)
+                loss.backward()
+        else:
+            loss = torch.nn.functional.cross_entropy(net.net(x), y)
+            loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), [p.grad.clone() for p in net.parameters()]
+
+    assert bnlink.PREMASK
+    bnlink.STATS.update(upstream=0, own=0)
+    loss1, g1 = grads()
+    # layered: the 7 identity blocks' inputs take their gradient from two operators; autograd's sum carries no tag, the
+    # BatchNorm in front launches its own sums and masks the (partly masked) sum again -- the fallback, same bits
+    assert bnlink.STATS["own"] == (7 if route == "layered" else 0)
+    monkeypatch.setattr(bnlink, "PREMASK", False)
+    loss0, g0 = grads()
+    assert loss0 == loss1
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
 @ALT
 def test_weight_gradients_on_a_side_stream_have_the_same_bits(monkeypatch):
     """conv.SIDE_STREAM (off by default: measured slower inside a replayed graph): the weight-gradient half of every
