@@ -480,6 +480,36 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+# Evaluation mode: conv3x3 -> BatchNorm (running statistics) -> (+ residual) -> ReLU in ONE launch (csrc/conv_hip.inc,
+# EvalBn): the BatchNorm is a per-channel affine map of the accumulator tile, so its launch, the convolution's output
+# tensor and the read of it disappear from every test-set forward; the bits of ``conv3x3`` followed by ``bn.bn_eval``.
+# SGMCMC_CONV_BN_EVAL=0 restores the two launches (A/B, the tests' cross-check).
+CONV_BN_EVAL = os.environ.get("SGMCMC_CONV_BN_EVAL", "1") != "0"
+
+
+def conv_bn_eval_supported(x, w, bias, conv_args, bn):
+    "a trunk 3x3 convolution followed by an eval-mode BatchNorm2d with running statistics, outside autograd"
+    from . import bn as _bn
+    return (CONV_BN_EVAL and not PERSISTENT and not bn.training and bn.track_running_stats
+            and supported(x, w, bias, *conv_args)
+            and _bn.eval_supported(x, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+
+
+def conv3x3_bn_eval(x, w, bn, residual=None, relu=False):
+    "relu?(bn_eval(conv3x3(x, w)) [+ residual]) -- sgmcmc_conv3x3_bn_eval"
+    x, w = x.contiguous(), w.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    y = torch.empty_like(x)
+    err = _hip.lib().sgmcmc_conv3x3_bn_eval(x.data_ptr(), w.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
+                                            0 if residual is None else residual.data_ptr(), int(bool(relu)), y.data_ptr(),
+                                            x.shape[0], x.shape[1], x.shape[2], _stream())
+    if err:
+        _hip.check(err, "sgmcmc_conv3x3_bn_eval")
+    return y
+
+
 def conv3x3(x, w, want_stats=False):
     """3x3 / stride 1 / zero-pad 1 convolution, no bias, for the (channels, side) pairs in SHAPES.
     ``want_stats``: also return the per-band (sum, sum of squared deviations from the band mean) of every output channel, float64

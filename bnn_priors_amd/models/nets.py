@@ -242,6 +242,10 @@ class _BatchNorm2d(nn.BatchNorm2d):
 def _conv_bn(conv, bn, x, residual=None, relu=False):
     "relu?(bn(conv(x)) [+ residual]); the convolution's epilogue hands the batch statistics to the BN"
     if isinstance(conv, Conv2d) and isinstance(bn, _BatchNorm2d):
+        if _conv.conv_bn_eval_supported(x, conv.weight, conv.bias, conv.conv_args, bn):
+            # a test-set forward: the BatchNorm (running statistics), the shortcut's add and the ReLU ride in the
+            # convolution's epilogue -- one launch (inference.py:199-213, exp_utils.py:250-340)
+            return _conv.conv3x3_bn_eval(x, conv.weight, bn, residual, relu)
         want = bn.training and bn.track_running_stats and _bn.ENABLED
         y, stats = conv(x, want_stats=True) if want else (conv(x), None)
         return bn.fused(y, residual, relu, stats)

@@ -384,6 +384,15 @@ int sgmcmc_conv3x3(const float* x, const float* w, float* y, int n_img, int chan
 int64_t sgmcmc_conv3x3_wrw_scratch_floats(int n_img, int channels, int hw);
 int sgmcmc_conv3x3_wrw(const float* x, const float* dy, float* dw, float* scratch, int n_img,
                        int channels, int hw, void* stream);
+/* Evaluation mode: y = relu?(BatchNorm_eval(conv3x3(x, w)) [+ residual]) in ONE launch -- with running statistics the
+ * BatchNorm that follows a convolution is a per-channel affine map, applied to the accumulator tile in the epilogue
+ * (invstd = 1 / sqrtf(var + eps); ((v - mean) * invstd) * gamma + beta; + residual; ReLU: sgmcmc_bn_eval_fwd's
+ * arithmetic on sgmcmc_conv3x3's output, the same bits as the two launches).  Replaces conv -> BatchNorm2d.eval() ->
+ * (+ shortcut) -> ReLU of models/google_resnet.py:34-56 inside the test-set passes (inference.py:199-213,
+ * exp_utils.py:250-340).  residual may be NULL; the three trunk shapes. */
+int sgmcmc_conv3x3_bn_eval(const float* x, const float* w, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, double eps, const float* residual,
+                           int relu, float* y, int n_img, int channels, int hw, void* stream);
 /* Both gradients in one launch (they are independent and share the GPU): dx as sgmcmc_conv3x3 with
  * transpose_w = 1 on dy, dw and scratch as sgmcmc_conv3x3_wrw.  Results are bit-identical to the two
  * separate calls.

@@ -120,3 +120,40 @@ def test_a_model_can_be_copied_and_pickled_after_evaluation_and_new_buffers_get_
     lps2, _, _, _ = ev.predictive_tables(net, loader, one)
     assert len(ev._eval_graphs[net]) == n_before + 1
     assert not torch.equal(lps0, lps2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [256, 5])
+def test_eval_batchnorm_in_the_convolution_epilogue_changes_no_bit(n, monkeypatch):
+    """Evaluation mode: conv3x3 -> BatchNorm (running statistics) -> (+ shortcut) -> ReLU is one launch
+    (sgmcmc_conv3x3_bn_eval: the BatchNorm applied to the accumulator tile); the logits of googleresnet carry the bits of
+    the separate launches (conv3x3 + bn_eval), and agree with PyTorch's own layers in float64."""
+    from bnn_priors_amd import conv
+    torch.manual_seed(3)
+    x = torch.randn(n, 3, 32, 32).cuda()
+    net = models.get_model(x.cpu()[:2], torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    models.he_initialize(net)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    net.eval()
+    calls = {"n": 0}
+    real = conv.conv3x3_bn_eval
+    monkeypatch.setattr(conv, "conv3x3_bn_eval", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), real(*a, **k))[1])
+    with torch.no_grad():
+        fused = net.net(x)
+        assert calls["n"] == 16            # every 3x3 of the trunk but the stem and the two strided ones
+        monkeypatch.setattr(conv, "CONV_BN_EVAL", False)
+        plain = net.net(x)
+        assert calls["n"] == 16
+    assert torch.equal(fused, plain)
+    ref = net.double()
+    monkeypatch.setattr(conv, "ENABLED", False)
+    with torch.no_grad():
+        want = ref.net(x.double())
+    torch.testing.assert_close(fused.double(), want, rtol=1e-4, atol=1e-4)
