@@ -255,8 +255,9 @@ def conv_rooflines(device, n_img=128, iters=60):
                                e_dout=0, e_out=0)
         fused_route = (not resblock.EPILOGUE_SUMS) and (c, hw) in resblock.FUSED_BN_BWD
         part = torch.empty((c, lib.sgmcmc_conv3x3_stat_slices(n_img, c, hw), 2), dtype=torch.float64, device=device)
+        # (as the step launches them since round 4: dx stored masked, the shortcut's gradient added as it arrives)
         E = _hip.ConvBwdEpilogue(s_y=y.data_ptr(), s_out=out.data_ptr(), s_mean=saved[0].data_ptr(),
-                                 s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr())
+                                 s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr(), mask_dx=1)
         n_convs = 6 if c == 16 else 5          # trunk convolutions of this shape in googleresnet (depth 20)
 
         def fwd():
@@ -272,8 +273,9 @@ def conv_rooflines(device, n_img=128, iters=60):
                                                  dw.data_ptr(), scratch.data_ptr(), n_img, c, hw, ctypes.byref(slabs),
                                                  stream), "sgmcmc_conv3x3_bwd_ex")
 
-        E2 = _hip.ConvBwdEpilogue(e_dout=dy.data_ptr(), e_out=out.data_ptr(), s_y=y.data_ptr(), s_out=out.data_ptr(),
-                                  s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr())
+        E2 = _hip.ConvBwdEpilogue(e_dout=dy.data_ptr(), e_out=0, s_y=y.data_ptr(), s_out=out.data_ptr(),
+                                  s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr(),
+                                  mask_dx=1)
 
         def bwd_add_sums():  # an identity block's FIRST convolution: + the shortcut's gradient in the epilogue
             _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E2),
@@ -366,7 +368,9 @@ def bn_rooflines(device, n_img=128, iters=60):
     producing convolution's statistics partials) and ``bn::bwd_dx_kernel`` (the whole BatchNorm backward given the
     sums partials of the upstream epilogue), at the three trunk stages, launched through the C ABI with the
     partials a convolution of the same shape leaves.  Algorithmic bytes per element: apply 8 (read y, write out;
-    12 with the residual), backward 16 (read dout, out, y; write dy).  21 + 21 launches per googleresnet step."""
+    12 with the residual), backward 12 (read dz, y; write dy -- since round 4 the launch that produces the incoming
+    gradient stores it masked, dz = dout * [out > 0], so the step's backward launches are the ReLU-less instantiation
+    and do not read `out`: bnlink.PREMASK).  21 + 21 launches per googleresnet step."""
     from bnn_priors_amd import _hip, bn as _bn, conv as _conv
     lib = _hip.lib()
     stream = torch.cuda.current_stream(device).cuda_stream
@@ -394,14 +398,14 @@ def bn_rooflines(device, n_img=128, iters=60):
                                      None, stats, slices, stream), "sgmcmc_bn_train_fwd")
 
         def bwd_dx():
-            _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(),
-                                            saved[0].data_ptr(), saved[1].data_ptr(), 1, n_img, c, hw * hw,
+            _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), 0, y.data_ptr(), gamma.data_ptr(),
+                                            saved[0].data_ptr(), saved[1].data_ptr(), 0, n_img, c, hw * hw,
                                             partial.data_ptr(), slices, dy.data_ptr(), 0, dgb.data_ptr(), None, 1,
                                             stream), "sgmcmc_bn_bwd_dx")
         for name, fn, nbytes, per_step in (
                 (f"bn::apply_kernel<relu> {c}@{hw}^2", lambda: apply(None), 8 * elems, (n_convs + 1) // 2 + (1 if c == 16 else 0)),
                 (f"bn::apply_kernel<relu,residual> {c}@{hw}^2", lambda: apply(res), 12 * elems, n_convs // 2 + (1 if c > 16 else 0)),
-                (f"bn::bwd_dx_kernel<relu> {c}@{hw}^2", bwd_dx, 16 * elems, n_convs + 1)):
+                (f"bn::bwd_dx_kernel<> {c}@{hw}^2", bwd_dx, 12 * elems, n_convs + 1 + (1 if c > 16 else 0))):
             for _ in range(5):
                 fn()
             torch.cuda.synchronize(device)

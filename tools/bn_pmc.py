@@ -41,8 +41,9 @@ for _ in range(a.iters):
                                            0.1, 1e-5, 1, n, c, hw * hw, out.data_ptr(), saved[0].data_ptr(),
                                            saved[1].data_ptr(), 0, stats.data_ptr(), slices, 1, s), "apply")
     flush.add_(1.0)
-    _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), out.data_ptr(), y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(),
-                                    saved[1].data_ptr(), 1, n, c, hw * hw, part.data_ptr(), slices, dx.data_ptr(), 0,
+    # (the step's backward launches: the incoming gradient arrives masked -- bnlink.PREMASK -- relu = 0, `out` not read)
+    _hip.check(lib.sgmcmc_bn_bwd_dx(dout.data_ptr(), 0, y.data_ptr(), gamma.data_ptr(), saved[0].data_ptr(),
+                                    saved[1].data_ptr(), 0, n, c, hw * hw, part.data_ptr(), slices, dx.data_ptr(), 0,
                                     dgb.data_ptr(), None, 1, s), "bwd_dx")
 torch.cuda.synchronize(dev)
 print("done")

@@ -53,11 +53,11 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
         _hip.check(lib.sgmcmc_conv3x3_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, scratch.data_ptr(),
                                           n, c, hw, ctypes.byref(slabs), s), "bwd")
         E = _hip.ConvBwdEpilogue(s_y=y.data_ptr(), s_out=out.data_ptr(), s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(),
-                                 s_partial=part.data_ptr())
+                                 s_partial=part.data_ptr(), mask_dx=1)
         _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E), 0,
                                              scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s), "bwd_ex")    # as the step runs it
-        E3 = _hip.ConvBwdEpilogue(e_dout=dy.data_ptr(), e_out=out.data_ptr(), s_y=y.data_ptr(), s_out=out.data_ptr(),
-                                  s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr())
+        E3 = _hip.ConvBwdEpilogue(e_dout=dy.data_ptr(), e_out=0, s_y=y.data_ptr(), s_out=out.data_ptr(),
+                                  s_mean=saved[0].data_ptr(), s_invstd=saved[1].data_ptr(), s_partial=part.data_ptr(), mask_dx=1)
         _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E3), 0,
                                              scratch.data_ptr(), n, c, hw, ctypes.byref(slabs), s), "bwd_ex(add)")   # an identity block's first convolution
         _hip.check(lib.sgmcmc_bn_bwd_sums(dy.data_ptr(), out.data_ptr(), y.data_ptr(), saved[0].data_ptr(),

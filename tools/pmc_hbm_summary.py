@@ -40,7 +40,9 @@ def algorithmic_bytes(name, grid):
         act = 4 * n * c * hw * hw
         if m.group(1) == "apply_kernel":      # reads x (+ residual), writes y
             return act * (2 if m.group(3) == "true" else 1), act
-        return 3 * act, act                   # reads dout, out (ReLU mask), x; writes dx
+        # reads dout, out (ReLU mask), x; writes dx -- the ReLU-less instantiation (the step's launches since round 4: the
+        # gradient arrives masked, bnlink.PREMASK) does not read `out`
+        return (3 if m.group(2) == "true" else 2) * act, act
     m = re.search(r"step_kernel(_stream|_indirect)?<float, \d+(, (true|false), (\d))?", name)
     if m:                                  # 28 B per element: 4 reads + 3 writes of 4 B
         items = 4 if (m.group(1) == "_stream" or m.group(4) is None) else int(m.group(4))
@@ -59,8 +61,9 @@ def algorithmic_bytes(name, grid):
         n = grid // 256 * 2 // (3 * (hw // 8) * (c // 16))
         act = 4 * n * c * hw * hw
         slabs = n * (hw // 8) // 2
-        extra = (2 * act if m.group(4) == "true" else 0) + (2 * act if m.group(5) == "true" else 0)   # epilogue operands
-        # reads x, dy, w (+ the shortcut's dout / out, + the next BatchNorm's y / out); writes dx + partial slabs
+        extra = (act if m.group(4) == "true" else 0) + (2 * act if m.group(5) == "true" else 0)   # epilogue operands
+        # reads x, dy, w (+ the shortcut's gradient -- stored masked by its producer since round 4: its activation is not
+        # read --, + the next BatchNorm's y / out); writes dx + partial slabs
         return 2 * act + 36 * c * c + extra, act + 36 * c * c * slabs
     m = re.search(r"fused_bwd_kernel<(\d+), (\d+), (\d+), (true|false)>", name)
     if m:
