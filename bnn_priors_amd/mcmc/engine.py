@@ -149,11 +149,23 @@ class Engine:
         flat = arena[off:off + p.numel()]
         return flat.view(p.shape) if p.is_contiguous() else flat.as_strided(p.shape, p.stride())
 
+    def views(self, name):
+        """every tensor's slice of the arena ``name`` (m, v, prev_theta, prev_g, prev_m), built ONCE per arena object: a
+        slice + view costs ~4 us of host time, and the optimizers handed out 130 - 330 of them per eager transition --
+        2.3 ms per Metropolis-Hastings point (final_step, sample_momentum, initial_step) during which the GPU waits for
+        the host (3 % of the HMC L = 50 cycle)"""
+        arena = getattr(self, name)
+        cache = self.__dict__.setdefault("_view_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] is not arena:
+            hit = cache[name] = (arena, [self._view(arena, i) for i in range(len(self.params))])
+        return hit[1]
+
     def momentum_view(self, i):
-        return self._view(self.m, i)
+        return self.views("m")[i]
 
     def square_avg_view(self, i):
-        return self._view(self.v, i)
+        return self.views("v")[i]
 
     def ensure_prev(self):
         if self.prev_theta is None:

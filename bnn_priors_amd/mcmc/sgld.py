@@ -62,8 +62,11 @@ class SGLD(torch.optim.Optimizer):
         return [self.state[p].setdefault('preconditioner', 1.) for p in self._engine.params]
 
     def _install_momentum_views(self):
+        views = self._engine.views("m")
         for i, p in enumerate(self._engine.params):
-            self.state[p]['momentum_buffer'] = self._engine.momentum_view(i)
+            st = self.state[p]
+            if dict.get(st, 'momentum_buffer') is not views[i]:
+                st['momentum_buffer'] = views[i]
 
     def _run_closure(self, closure):
         if closure is None:
@@ -75,16 +78,16 @@ class SGLD(torch.optim.Optimizer):
         """tests and users may rebind state['momentum_buffer'] to their own tensor;
         copy such a tensor into the arena and restore the view."""
         eng = self._engine
+        vm, vv = eng.views("m"), eng.views("v")
         for i, p in enumerate(eng.params):
             st = self.state[p]
-            for key, view_of in (('momentum_buffer', eng.momentum_view), ('square_avg', eng.square_avg_view)):
+            for key, view in (('momentum_buffer', vm[i]), ('square_avg', vv[i])):
                 t = dict.get(st, key)
-                if t is None:
+                if t is None or t is view:              # (the cached view itself: nothing was rebound)
                     continue
-                view = view_of(i)
                 if t.data_ptr() != view.data_ptr():     # e.g. after load_state_dict
                     view.copy_(t)
-                    dict.__setitem__(st, key, view)
+                dict.__setitem__(st, key, view)
 
     # set by the runners: the non-finite flag stays on the device and is tested at metric steps / epoch
     # ends (inference.SGLDRunner._check_finite) instead of with one host sync after every launch

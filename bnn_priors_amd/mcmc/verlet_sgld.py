@@ -56,11 +56,11 @@ class VerletSGLD(SGLD):
         if flags & _hip.CALC_METRICS:
             eng.metrics_ready = True
         if flags & _hip.SAVE_STATE:
+            pt, pg, pm = eng.views("prev_theta"), eng.views("prev_g"), eng.views("prev_m")
             for i, p in enumerate(eng.params):
                 st = self.state[p]
-                st['prev_parameter'] = eng._view(eng.prev_theta, i)
-                st['prev_grad'] = eng._view(eng.prev_g, i)
-                st['prev_momentum_buffer'] = eng._view(eng.prev_m, i)
+                if dict.get(st, 'prev_parameter') is not pt[i]:
+                    st['prev_parameter'], st['prev_grad'], st['prev_momentum_buffer'] = pt[i], pg[i], pm[i]
         return loss
 
     # ------------------------------------------------------------------ reference API
