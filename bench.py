@@ -947,7 +947,7 @@ def main():
             # the kernel with the largest share of the step, the sampler's HBM line is reported beside it
             convs = attach_pmc_traffic(conv_rooflines(device))
             try:
-                bns = bn_rooflines(device)
+                bns = attach_pmc_traffic(bn_rooflines(device))
             except Exception as exc:       # (an extra table: never takes the bench line down)
                 bns = []
                 out["roofline_bn_error"] = f"{type(exc).__name__}: {exc}"

@@ -322,3 +322,37 @@ def test_errors_match_reference():
     sg = mcmc.SGLD([p], lr=0.1, num_data=1, momentum=0.5)
     with pytest.raises(AssertionError):
         sg.step(save_state=True)
+
+
+def test_state_views_are_built_once_and_rebound_tensors_are_adopted():
+    """``state[p]['momentum_buffer']`` etc. are views of the engine's arenas, built once per arena (engine.views): the
+    same objects after every transition; a tensor a user rebinds the key to (the reference's samplers own plain tensors:
+    mcmc/sgld.py:57-69) is copied into the arena at the next transition and the view is restored -- the same parameters,
+    bit for bit, as writing the values into the view in place."""
+    mcmc, models = _imports()
+
+    def run(rebind):
+        torch.manual_seed(11)
+        model = models.GaussianModel(N=1, D=7, mean=0.5, std=0.25).to(DEV)
+        opt = mcmc.VerletSGLD(model.parameters(), lr=0.01, num_data=1, momentum=0.9, temperature=1., seed=3)
+        opt.sample_momentum()
+        opt.initial_step(model.potential_avg_closure, save_state=True)
+        p = next(iter(model.parameters()))
+        keys = ("momentum_buffer", "prev_parameter", "prev_grad", "prev_momentum_buffer")
+        views = {k: opt.state[p][k] for k in keys}
+        opt.step(model.potential_avg_closure)
+        opt.final_step(model.potential_avg_closure)
+        opt.sample_momentum()
+        opt.initial_step(model.potential_avg_closure, save_state=True)
+        for k, v in views.items():
+            assert opt.state[p][k] is v, k
+        if rebind:
+            opt.state[p]["momentum_buffer"] = torch.full_like(p, 0.25)
+        else:
+            opt.state[p]["momentum_buffer"].fill_(0.25)
+        opt.step(model.potential_avg_closure, calc_metrics=False)
+        assert opt.state[p]["momentum_buffer"] is views["momentum_buffer"]
+        return p.detach().clone(), opt.state[p]["momentum_buffer"].clone()
+
+    (ta, ma), (tb, mb) = run(True), run(False)
+    assert torch.equal(ta, tb) and torch.equal(ma, mb)

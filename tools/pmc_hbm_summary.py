@@ -54,7 +54,7 @@ def algorithmic_bytes(name, grid):
         n = grid // 256 // ((hw // 8) * (c // 16))
         act = 4 * n * c * hw * hw
         return act + 36 * c * c, act
-    m = re.search(r"conv3x3_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", name)
+    m = re.search(r"conv3x3_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)(?:, (?:true|false))?>", name)
     if m:
         c, hw = int(m.group(1)), int(m.group(2))
         # grid = dgrad blocks (n * bands * ct) + wrw blocks (n * bands / 2 * ct)

@@ -68,8 +68,8 @@ def row_name(rows_of_step, i):
     m = re.search(r"conv::conv3x3_kernel<(\d+), (\d+), (\d+), false, true>", name)
     if m:
         return "conv::conv3x3_kernel<%s,%s,%s,stats>" % m.groups()
-    m = re.search(r"conv::conv3x3_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", name)
-    if m:
+    m = re.search(r"conv::conv3x3_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)(?:, (?:true|false))?>", name)
+    if m:       # (a third flag since round 4: the many-minibatch instantiation; the step runs `false`)
         c, hw, r, epi, sums = m.groups()
         tag = ",".join(t for t, on in (("ADD", epi), ("SUMS", sums)) if on == "true")
         return "conv::conv3x3_bwd_kernel<%s,%s,%s%s>" % (c, hw, r, "," + tag if tag else "")
