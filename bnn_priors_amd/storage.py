@@ -51,12 +51,37 @@ class MemoryMetrics:
         return [k for k in out if k != "timestamps"]
 
 
+def state_dict_to_host(state_dict):
+    """{k: CPU tensor} of a state dict whose tensors live on a GPU, with ONE device-to-host copy per (device, dtype)
+    instead of one per tensor: the tensors of a group are concatenated on the device (one launch), copied, and handed
+    out as views of the host buffer.  A googleresnet sample is 65 parameters + 63 BatchNorm buffers: 128 synchronous
+    copies of a few KB each took 4-5 ms of every stored sample (exp_utils.py:489-509 copies tensor by tensor on the
+    host it runs on).  Same values; tensors already on the host are passed through detached."""
+    out, groups = {}, OrderedDict()
+    for k, v in state_dict.items():
+        v = v.detach()
+        if v.is_cuda:
+            groups.setdefault((v.device, v.dtype), []).append((k, v))
+        else:
+            out[k] = v
+    for items in groups.values():
+        if len(items) == 1:
+            out[items[0][0]] = items[0][1].cpu()
+            continue
+        flat = torch.cat([v.reshape(-1) for _, v in items]).cpu()
+        at = 0
+        for k, v in items:
+            out[k] = flat[at:at + v.numel()].view(v.shape)
+            at += v.numel()
+    return {k: out[k] for k in state_dict}       # (the caller's key order: the first write creates the datasets in it)
+
+
 class MemoryModelSaver:
     def __init__(self):
         self.samples, self.steps, self.timestamps = [], [], []
 
     def add_state_dict(self, state_dict, step):
-        self.samples.append({k: v.detach().cpu().clone() for k, v in state_dict.items()})
+        self.samples.append({k: v.clone() for k, v in state_dict_to_host(state_dict).items()})
         self.steps.append(step)
         self.timestamps.append(time.time())
 
@@ -132,7 +157,7 @@ class HDF5ModelSaver:
             self.f.close()
 
     def add_state_dict(self, state_dict, step):
-        rows = {k: v.detach().cpu().unsqueeze(0).numpy() for k, v in state_dict.items()}
+        rows = {k: v.unsqueeze(0).numpy() for k, v in state_dict_to_host(state_dict).items()}
         rows["steps"] = np.array([step], dtype=np.int64)
         rows["timestamps"] = np.array([time.time()], dtype=np.float64)
         self._i += self._write_at_cursor(rows)

@@ -204,3 +204,21 @@ def test_runner_through_hdf5_sinks_matches_memory_sinks(tmp_path):
         assert f["acceptance/rejected"].dtype == np.int64
     s = storage.load_samples(tmp_path / "samples.h5")
     assert s["steps"].tolist() == [17, 34]
+
+
+@pytest.mark.gpu
+def test_a_device_state_dict_reaches_the_host_in_one_copy_per_dtype_with_the_same_values():
+    "storage.state_dict_to_host: concatenated on the device, copied once, split into views -- key order and values kept"
+    import torch
+    from bnn_priors_amd import models
+    from bnn_priors_amd.storage import state_dict_to_host
+    x = torch.randn(2, 3, 32, 32)
+    net = models.get_model(x, torch.tensor([0, 9]), "googleresnet", width=50, depth=3, weight_prior="gaussian",
+                           weight_scale=2 ** .5, bias_prior="gaussian", bias_scale=1.).cuda()
+    sd = net.state_dict()
+    sd["strided"] = torch.randn(6, 4, device="cuda").t()           # (a non-contiguous entry)
+    host = state_dict_to_host(sd)
+    assert list(host) == list(sd)
+    for k, v in sd.items():
+        assert not host[k].is_cuda and host[k].dtype == v.dtype and host[k].shape == v.shape
+        assert torch.equal(host[k], v.cpu()), k
