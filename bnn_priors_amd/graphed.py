@@ -173,7 +173,7 @@ class GraphedLeapfrog(_ReportSlots):
     def _body(self, capturing, metrics):
         self.opt.zero_grad()
         with _conv.deferring(self.model):
-            with _pool.head_loss(self.y):
+            with _pool.head_loss(self.y, head=_pool.head_of(self.pot.model)):
                 f = self.pot._logits(self.x)
             loss = _pool.cross_entropy_backward(f, self.y, want_loss=metrics)
         with torch.no_grad():
@@ -365,7 +365,7 @@ class GraphedAccumulate:
         # (several minibatches per launch: the persistent convolutions, csrc/conv2_hip.inc -- see conv.persistent)
         with self._logging(), _bn.grouped(group), _conv.persistent(group > 1 and EXACT_PERSISTENT), \
                 _conv.deferring(self.model):
-            with _pool.head_loss(y, "sum", self.pot.N):
+            with _pool.head_loss(y, "sum", self.pot.N, head=_pool.head_of(self.pot.model)):
                 f = self.pot._logits(x)
             this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.pot.N)
         got = [(a, p.grad) for a, p in zip(self.grads, params) if p.grad is not None]   # hyper-parameters: none

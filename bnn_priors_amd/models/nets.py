@@ -49,7 +49,7 @@ class Linear(_PriorBacked):
     def forward(self, x):
         w, b = self.weight, self.bias
         if _pool.linear_supported(x, w, b):        # a head with a few outputs: one launch each way (pool.linear)
-            return _pool.linear(x, w, b)
+            return _pool.linear(x, w, b, owner=self)
         _conv.library_path("linear", x)
         return nn.functional.linear(x, w, b)
 

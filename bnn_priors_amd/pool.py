@@ -119,13 +119,30 @@ _head = {"spec": None, "last": None, "counted": False}
 
 
 @contextlib.contextmanager
-def head_loss(y, reduction="mean", divide_by=None):
-    old = _head["spec"]
-    _head["spec"] = (y, reduction, divide_by)
+def head_loss(y, reduction="mean", divide_by=None, head=None):
+    """``head``: the module whose launch may take the likelihood (``head_of(model)``: the net's LAST linear layer).  A
+    narrow hidden ``Linear`` (<= 16 outputs, a user's ``width``) passes ``linear_supported`` too; without this it would
+    compute a softmax and a loss row nobody reads.  None: any supported layer (direct callers of ``pool.linear``)."""
+    old = _head["spec"], _head.get("head")
+    _head["spec"], _head["head"] = (y, reduction, divide_by), head
     try:
         yield
     finally:
-        _head["spec"] = old
+        _head["spec"], _head["head"] = old
+
+
+def head_of(model):
+    "the last module of ``model.net`` with a ``weight_prior`` and 2-D weights (models/nets.py Linear), cached on the net"
+    net = getattr(model, "net", model)
+    hit = net.__dict__.get("_sgmcmc_head")
+    if hit is None:
+        last = None
+        for m in net.modules():
+            wp = getattr(m, "weight_prior", None)
+            if wp is not None and getattr(getattr(wp, "p", None), "dim", lambda: 0)() == 2:
+                last = m
+        hit = net.__dict__["_sgmcmc_head"] = (last,)
+    return hit[0]
 
 
 def _grad_scale(rows, reduction, divide_by):
@@ -257,14 +274,15 @@ def linear_supported(x, weight, bias):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, owner=None):
         _conv._note_use(weight)
         x, weight = x.contiguous(), weight.contiguous()
         n, k = x.shape[0], weight.shape[0]
         y = torch.empty((n, k), dtype=torch.float32, device=x.device)
         spec = _head["spec"]
         _head["last"] = None
-        if (FUSED_HEAD and spec is not None and n <= 1024 and spec[0].is_cuda and spec[0].dtype == torch.int64
+        is_head = _head.get("head") is None or _head["head"] is owner
+        if (FUSED_HEAD and spec is not None and is_head and n <= 1024 and spec[0].is_cuda and spec[0].dtype == torch.int64
                 and spec[0].dim() == 1 and spec[0].shape[0] == n and spec[1] in ("mean", "sum")
                 and any(ctx.needs_input_grad)):
             # ``head_loss``: the likelihood's forward + seed in the last layer's launch (the backward stays lin::bwd)
@@ -310,12 +328,12 @@ class _Linear(torch.autograd.Function):
         dw = None
         if slabs is not None:     # the row groups' slabs: summed with the pass's other slabs when nothing reads dw earlier
             dw = _reduce_rows(slabs.view(slabs.shape[0], -1), torch.empty_like(weight), _conv._may_defer(weight))
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
-    "F.linear(x, weight, bias) for 2-D float32 x and at most 16 output features"
-    y = _Linear.apply(x, weight, bias)
+def linear(x, weight, bias=None, owner=None):
+    "F.linear(x, weight, bias) for 2-D float32 x and at most 16 output features; ``owner``: the calling module (``head_loss``)"
+    y = _Linear.apply(x, weight, bias, owner)
     if _head["last"] is not None:          # (``head_loss`` was active: the launch also produced the likelihood's seed)
         y._sgmcmc_head_loss = _head["last"] + (y._version,)
         _head["last"] = None

@@ -59,7 +59,7 @@ class Potential:
         with _conv.deferring(self.model):      # this pass's convolution weight-gradient slabs: one reduction at its end
             extra = self._leftover_log_prior()
             if extra is None:
-                with _pool.head_loss(y):                        # a fused head also takes the loss and both backward passes
+                with _pool.head_loss(y, head=_pool.head_of(self.model)):                        # a fused head also takes the loss and both backward passes
                     f = self._logits(x)
                 loss = _pool.cross_entropy_backward(f, y)       # likelihood forward + backward seed: one launch
             else:
@@ -139,7 +139,7 @@ class Potential:
                 (acc.add if acc.matches(x, y) else acc.add_eager)(x, y)
             else:
                 # (gradients accumulate into existing .grad tensors here, so nothing is deferred)
-                with _pool.head_loss(y, "sum", self.N):
+                with _pool.head_loss(y, "sum", self.N, head=_pool.head_of(self.model)):
                     f = self._logits(x)
                 this = _pool.cross_entropy_backward(f, y, reduction="sum", divide_by=self.N)
                 loss = loss + this.double()

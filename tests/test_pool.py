@@ -262,3 +262,31 @@ def test_fused_linear_forward_and_loss_equals_the_two_kernels(n, reduction, divi
             torch.testing.assert_close(a, b_, rtol=1e-6, atol=0)
         else:
             assert torch.equal(a, b_), name
+
+
+@pytest.mark.gpu
+def test_only_the_last_linear_layer_takes_the_likelihood():
+    """A narrow hidden Linear (<= 16 outputs) passes ``linear_supported`` too: with ``head_loss(..., head=head_of(model))``
+    only the net's LAST linear layer computes the loss rows and the seed; the hidden one runs the plain forward."""
+    from bnn_priors_amd import pool, prior
+    from bnn_priors_amd.models import nets
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(nets.LinearPrior(40, 8), torch.nn.ReLU(), nets.LinearPrior(8, 10)).cuda()
+    model = type("M", (), {"net": net})()
+    assert pool.head_of(model) is net[2] and pool.head_of(model) is net[2]        # (cached)
+    x = torch.randn(32, 40).cuda()
+    y = torch.randint(0, 10, (32,)).cuda()
+    seen = {}
+    for i in (0, 2):
+        net[i].register_forward_hook(lambda m, a, out, i=i: seen.__setitem__(i, hasattr(out, "_sgmcmc_head_loss")))
+    with pool.head_loss(y, head=pool.head_of(model)):
+        f = net(x)
+    assert seen == {0: False, 2: True}
+    loss = pool.cross_entropy_backward(f, y)
+    ref = torch.nn.functional.cross_entropy(
+        torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, net[0].weight, net[0].bias)),
+                                   net[2].weight, net[2].bias), y)
+    torch.testing.assert_close(loss, ref.detach(), rtol=1e-5, atol=1e-6)
+    with pool.head_loss(y):                       # no head named: any supported layer (direct callers)
+        net(x)
+    assert seen == {0: True, 2: True}
