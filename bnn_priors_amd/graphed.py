@@ -435,6 +435,8 @@ def pick_group(n_full, rows, lanes, want=None):
         if best_key is None or key < best_key:
             best, best_key = g, key
     return best
+# a group's G minibatches gathered (+ cropped / flipped) into the lane's static input by ONE launch instead of G
+GROUP_GATHER = os.environ.get("SGMCMC_EXACT_GROUP_GATHER", "1") != "0"
 EXACT_PERSISTENT = os.environ.get("SGMCMC_EXACT_PERSISTENT", "1") != "0"     # grouped bodies on the persistent convolutions
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
@@ -515,9 +517,13 @@ class ConcurrentAccumulate:
         G, n_lanes = self.group, len(self.streams)
         n_full = batches.n_full_batches() if hasattr(batches, "n_full_batches") else None
         n_groups = n_full // G if (G > 1 and n_full is not None) else 0
-        target = {"dst": None}
-        filling = batches.filling(lambda rows: target["dst"](rows) if target["dst"] else None) \
-            if hasattr(batches, "filling") else contextlib.nullcontext()
+        target = {"dst": None, "grp": None}
+        try:       # (a source that can gather a whole group with one launch: inference._BatchSource)
+            filling = batches.filling(lambda rows: target["dst"](rows) if target["dst"] else None,
+                                      group=(G, lambda rows: target["grp"](rows) if target["grp"] else None)) \
+                if hasattr(batches, "filling") else contextlib.nullcontext()
+        except TypeError:
+            filling = batches.filling(lambda rows: target["dst"](rows) if target["dst"] else None)
         with filling:
             it = iter(batches)
             turn = 0
@@ -528,9 +534,11 @@ class ConcurrentAccumulate:
                 lane = self.lanes[k]
                 self._room(G)
                 with torch.cuda.stream(self.streams[k]):
+                    target["grp"] = (lambda rows: (lane.x, lane.y) if rows == G * lane.rows else None) if GROUP_GATHER else None
                     for j in range(G):
                         target["dst"] = lambda rows, j=j: lane.slot(j) if rows == lane.rows else None
                         x, y = next(it)
+                        target["grp"] = None
                         if not lane.matches(x, y):      # (the contract of n_full_batches: the FIRST n_full ones are full)
                             raise RuntimeError("a batch source that announces its full-size minibatches must yield them "
                                                f"first: got {tuple(x.shape)} inside a group of {lane.shape[0]}")

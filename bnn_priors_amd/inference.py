@@ -169,15 +169,30 @@ class _BatchSource:
     # written into the (x_dst, y_dst) pair that ``provider(rows)`` returns (contiguous tensors of the batch's shape and
     # dtype, e.g. slices of a captured graph's static inputs) and those are what the iteration yields; None from the
     # provider (or no provider) = freshly allocated tensors as always.  Same minibatches, same RNG consumption.
+    # ``group=(G, group_provider)``: whenever G consecutive full-size minibatches are about to be produced and
+    # ``group_provider(G * rows)`` returns an (x_dst, y_dst) pair of G * rows rows, ALL of them are gathered by one launch
+    # (the rows are consecutive in the traversal order; the augmentation is keyed by data-set row and traversal, not by
+    # position in a launch: the same bytes as G gathers) and yielded one by one as views of that pair.
     _provider = None
+    _group = None
 
     @contextlib.contextmanager
-    def filling(self, provider):
-        old, self._provider = self._provider, provider
+    def filling(self, provider, group=None):
+        old, self._provider, self._group = (self._provider, self._group), provider, group
         try:
             yield self
         finally:
-            self._provider = old
+            self._provider, self._group = old
+
+    def _group_dst(self, i, n, bs):
+        "(G, x_dst, y_dst) when a whole group of full-size minibatches starting at row i can be gathered at once, else None"
+        if self._group is None:
+            return None
+        G, provider = self._group
+        if G <= 1 or i + G * bs > (n // bs) * bs:
+            return None
+        d = provider(G * bs)
+        return None if d is None else (G, d[0], d[1])
 
     def n_full_batches(self):
         """how many of this source's minibatches have the full batch size -- and come FIRST, in every traversal (the
@@ -262,8 +277,16 @@ class _BatchSource:
             draw = self.dl.dataset.next_draw()
             order = perm if perm is not None else torch.arange(n)
             order = order.to(self.device)
-            for i in range(0, stop, bs):
+            i = 0
+            while i < stop:
+                grp = None if lazy else self._group_dst(i, n, bs)
+                if grp is not None and self._stage_into(order[i:i + grp[0] * bs], draw, grp[1], grp[2]):
+                    for j in range(grp[0]):         # (G minibatches gathered by ONE launch)
+                        yield grp[1][j * bs:(j + 1) * bs], grp[2][j * bs:(j + 1) * bs]
+                    i += grp[0] * bs
+                    continue
                 idx = order[i:i + bs]
+                i += bs
                 if lazy:
                     yield LazyBatch(self, idx, draw), None
                     continue
@@ -290,7 +313,18 @@ class _BatchSource:
                 yield LazyBatch(self, order[i:i + bs], None), None
             self._exhausted(gen)
             return
-        for i in range(0, stop, bs):
+        i = -bs
+        skip_to = 0
+        while i + bs < stop:
+            i += bs
+            if i < skip_to:
+                continue
+            grp = self._group_dst(i, n, bs) if perm is not None else None
+            if grp is not None and self._stage_into(perm[i:i + grp[0] * bs], None, grp[1], grp[2]):
+                for j in range(grp[0]):
+                    yield grp[1][j * bs:(j + 1) * bs], grp[2][j * bs:(j + 1) * bs]
+                skip_to = i + grp[0] * bs
+                continue
             xd, yd = self._dst(min(bs, n - i))
             if perm is None:
                 if xd is None:
