@@ -57,3 +57,40 @@ def test_filling_writes_minibatches_into_the_consumers_buffers():
     assert src._provider is None
     for (gx, gy), (px, py) in zip(got, plain):
         assert torch.equal(gx, px) and torch.equal(gy, py)
+
+
+def test_a_group_provider_changes_nothing_where_a_group_cannot_be_gathered_at_once():
+    """``filling(provider, group=(G, group_provider))``: on a source that cannot gather on the device (the CPU here) the
+    group provider is asked, declined by ``_stage_into``, and every minibatch takes the ordinary route -- same rows."""
+    torch.manual_seed(9)
+    src, x, y = _source(True, n=700)
+    plain = [(a.clone(), b.clone()) for a, b in src]
+    torch.manual_seed(9)
+    src, _, _ = _source(True, n=700)
+    gx, gy = torch.zeros(256, 7), torch.zeros(256, dtype=torch.int64)
+    asked = []
+    with src.filling(lambda rows: None, group=(2, lambda rows: (asked.append(rows), (gx, gy))[1])):
+        got = [(a.clone(), b.clone()) for a, b in src]
+    assert src._provider is None and src._group is None
+    assert asked and all(r == 256 for r in asked)
+    assert len(got) == len(plain) == 6
+    for (a, b), (px, py) in zip(got, plain):
+        assert torch.equal(a, px) and torch.equal(b, py)
+
+
+def test_gradient_tags_carry_the_masked_flag_and_die_with_the_tensor_version():
+    "bnlink: (partial, n, masked) while the gradient tensor is untouched; an in-place change or a disabled link: None"
+    from bnn_priors_amd import bnlink
+    t = torch.zeros(4)
+    part = torch.zeros(2, 3, 2, dtype=torch.float64)
+    assert bnlink.sums_of(t) is None
+    bnlink.tag_gradient(t, part, 3, masked=True)
+    got = bnlink.sums_of(t)
+    assert got[0] is part and got[1] == 3 and got[2] is True
+    bnlink.tag_gradient(t, part, 3)
+    assert bnlink.sums_of(t)[2] is False
+    t.add_(1.0)
+    assert bnlink.sums_of(t) is None
+    out = torch.ones(2, 3)
+    bnlink.tag_output(out, torch.zeros(2, 3), torch.zeros(2, 3))
+    assert bnlink.source_of(out)[0] is not None and bnlink.source_of(torch.ones(2, 3)) == (None, None)
