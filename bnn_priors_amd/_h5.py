@@ -164,8 +164,15 @@ class Dataset:
         except KeyError:
             raise HDF5Error(f"dataset {name!r}: unsupported element type (class {cls}, {size} bytes)")
 
+    # A file this process writes changes its extents through ``resize`` alone: the shape is queried once and kept (a stored
+    # sample is ~170 datasets, each asked for its shape three times per row: a quarter of the store's time).  A SWMR
+    # reader refreshes and asks every time.
+    _shape = None
+
     @property
     def shape(self):
+        if self._shape is not None and not self.file.swmr_read:
+            return self._shape
         L = lib()
         if self.file.swmr_read:
             L.H5Drefresh(self.h)
@@ -174,7 +181,10 @@ class Dataset:
         d = (hsize_t * max(n, 1))()
         L.H5Sget_simple_extent_dims(s, d, None)
         L.H5Sclose(s)
-        return tuple(int(d[i]) for i in range(n))
+        shape = tuple(int(d[i]) for i in range(n))
+        if not self.file.swmr_read:
+            self._shape = shape
+        return shape
 
     def __len__(self):
         return self.shape[0]
@@ -182,6 +192,8 @@ class Dataset:
     def resize(self, n):
         shp = self.shape
         _chk(lib().H5Dset_extent(self.h, _dims((n,) + shp[1:])), f"H5Dset_extent({self.name})")
+        if self._shape is not None:
+            self._shape = (n,) + shp[1:]
 
     def _slab(self, start, count, shape):
         L = lib()
