@@ -107,7 +107,7 @@ class _ReportSlots:
 
 
 class GraphedLeapfrog(_ReportSlots):
-    def __init__(self, potential, optimizer, x_example, y_example, ring=8, warmup=2):
+    def __init__(self, potential, optimizer, x_example, y_example, ring=16, warmup=2):
         if not potential.fast or potential.leftover:
             raise ValueError("graph capture needs the fused-prior / cross-entropy potential")
         if len(optimizer.param_groups) != 1:
@@ -121,7 +121,12 @@ class GraphedLeapfrog(_ReportSlots):
         nbytes = ctypes.sizeof(_hip.StepArgs)
         self.args_dev = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self._slots = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(ring)]
-        self._slot_events = [None] * ring
+        # Slot reuse is guarded by an event recorded every ring / 2 steps, not after every staging launch: a
+        # hipEventRecord between that launch and the graph replay put 5.8 us of idle GPU between them (tools/
+        # gaps_around_staging.py: 5.8 -> 0.0 us; the convolutional classifier's step 123.2 -> 118.3 us).  Step k writes slot
+        # k mod ring, last read by step k - ring: free once an event recorded at a step >= k - ring has completed.
+        self._ring_events = {}
+        self._every = max(1, ring // 2)
         self._k = 0
         # closed-form priors without linked scales: the update kernel adds their gradient in flight (and leaves the
         # log-density partials on metric steps) -- no prior launch in the captured step
@@ -135,11 +140,16 @@ class GraphedLeapfrog(_ReportSlots):
     def _push_args(self, A, x=None, y=None):
         """The step's argument block into its device copy through a pinned ring slot -- and, with it, the
         minibatch into the graph's static inputs: ONE launch (``sgmcmc_stage_batch``) for all three."""
-        i = self._k % len(self._slots)
+        k, ring, every = self._k, len(self._slots), self._every
+        i = k % ring
         self._k += 1
-        ev = self._slot_events[i]
-        if ev is not None:
-            ev.synchronize()            # the copy that last used this slot has executed
+        if k >= ring:
+            j = ((k - ring) // every) * every + every - 1       # the first recording step at or after k - ring (< k)
+            ev = self._ring_events.get(j)
+            if ev is not None:
+                ev.synchronize()        # the launch that last read this slot has executed
+                for old in [q for q in self._ring_events if q < j]:
+                    del self._ring_events[old]
         ctypes.memmove(self._slots[i].data_ptr(), ctypes.addressof(A), ctypes.sizeof(A))
         if y is None and x is not None and hasattr(x, "stage"):
             # a LazyBatch: gathered (and augmented) straight into the static inputs by the launch that also copies the
@@ -153,8 +163,9 @@ class GraphedLeapfrog(_ReportSlots):
             x.stage(self.x, self.y, jobs, eng.layout, pending, torch.cuda.current_stream(self.x.device).cuda_stream)
         else:
             stage_batch(self.x, x, self.y, y, self.args_dev, self._slots[i], self.eng)
-        ev = self._slot_events[i] = ev or torch.cuda.Event()
-        ev.record()
+        if k % every == every - 1:
+            ev = self._ring_events[k] = torch.cuda.Event()
+            ev.record()
 
     def _args(self, calc_metrics=False, variant=None):
         "``variant``: which captured graph runs the step (default: the one named by ``calc_metrics``)"
