@@ -105,6 +105,9 @@ def parse():
                          "SGMCMC_STRICT=0 in the environment, and the line says so in config.step_path")
     ap.add_argument("--eval-rows", type=int, default=10000,
                     help="rows of the synthetic test set of `samples_per_sec_with_eval` (CIFAR-10's test set: 10,000)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="side file of the FULL record (per-kernel roofline rows, other workloads, timing, chains per GPU, "
+                         "calibration); stdout carries only the compact line (< 4 KB)")
     ap.add_argument("--stream-chains", default=None,
                     help="googleresnet / convnet: aggregate steps/s of K chains on K HIP streams of ONE GPU, e.g. '1,2,3' "
                          "(after the timed region; default: '1,2' for a one-GPU googleresnet run, '' = skip)")
@@ -314,6 +317,13 @@ def conv_rooflines(device, n_img=128, iters=60):
     return rows
 
 
+def _stale(committed):
+    """True when a committed measurement (profiles/in_step_us.json, pmc_traffic.json) was taken on other kernel sources
+    than this tree's: its ``source_sha`` (hash of csrc/* + include/*, bnn_priors_amd._hip.source_sha) differs or is absent."""
+    from bnn_priors_amd import _hip
+    return committed.get("source_sha") != _hip.source_sha()
+
+
 def attach_pmc_traffic(rows):
     """`traffic` of the rows that profiles/pmc_traffic.json covers: HBM bytes per launch from a rocprofv3 --pmc pass
     (FETCH_SIZE doubled as the guide prescribes for gfx950, + WRITE_SIZE) over the same kernels at the same shapes.
@@ -325,9 +335,13 @@ def attach_pmc_traffic(rows):
             pmc = json.load(f)
     except (OSError, ValueError):
         return rows
+    stale = _stale(pmc)
     for r in rows:
         k = pmc.get("kernels", {}).get(r.get("kernel"))
         if k and r.get("shape", {}).get("n") == 128:
+            if stale:           # counters of OTHER kernels than this tree's: not this launch's traffic
+                r["traffic_stale"] = True
+                continue
             r["traffic"] = k["read_bytes"] + k["write_bytes"]
             r["traffic_unit"] = "bytes per launch (HBM read + write)"
             if "traffic_over_algorithmic" in k:
@@ -349,9 +363,13 @@ def attach_in_step(rows):
             prof = json.load(f)
     except (OSError, ValueError):
         return rows
+    stale = _stale(prof)
     for r in rows:
         k = prof.get("kernels", {}).get(r.get("kernel"))
         if k and r.get("shape", {}).get("n") == 128:
+            if stale:           # durations of OTHER kernels than this tree's: no in-step columns, the live figure stays
+                r["stale"] = True
+                continue
             r["in_step_us"] = k["in_step_us"]
             r["in_step_launches_per_step"] = k["launches_per_step"]
             work = r.get("algorithmic_flops_per_launch") or r.get("algorithmic_bytes_per_launch")
@@ -669,8 +687,129 @@ def pin_process(local, local_world):
         return None
 
 
+# ------------------------------------------------------------------ --gpus N starts N ranks by itself
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: re-execute this command line under
+    ``torch.distributed.run --nproc-per-node N`` (one process per chain per GPU, as the reference starts one process per
+    replicate chain, experiments/run_experiment.sh:15-34).  Rank 0's one JSON line passes through on stdout.  Returns
+    the exit code of the launcher, or None when this process is itself a rank (or N = 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible; RCCL needs one device per rank "
+                         "(--backend gloo lets ranks share a GPU: a plumbing check, never a scaling number)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting", args.gpus, "ranks:", " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd)
+
+
+# ------------------------------------------------------------------ the headline roofline row and the compact line
+def _symbol(row):
+    "the device symbol a roofline row belongs to: BatchNorm rows of the three stages are ONE kernel, convolutions one per shape"
+    return row["kernel"].split(" ")[0]
+
+
+def headline_rooflines(rows):
+    """(top, top_other): the SYMBOL with the largest time per step -- all its rows (shapes) pooled: work summed over
+    launches / time summed over launches -- and the largest symbol of the other roofline kind (HBM vs MFMA), so that the
+    line names the real largest consumer AND the top contraction."""
+    groups = {}
+    for r in rows:
+        if not r.get("launches_per_step"):
+            continue
+        groups.setdefault(_symbol(r), []).append(r)
+
+    def pooled(sym, rs):
+        def tot(key_us):
+            return sum(r.get(key_us, r["avg_kernel_us"]) * r["launches_per_step"] for r in rs)
+        work_key = "algorithmic_flops_per_launch" if rs[0]["bound"] == "mfma" else "algorithmic_bytes_per_launch"
+        scale = 1e12 if rs[0]["bound"] == "mfma" else 1e9
+        n = sum(r["launches_per_step"] for r in rs)
+        work = sum(r[work_key] * r["launches_per_step"] for r in rs)
+        live_us, step_us = tot("avg_kernel_us"), tot("in_step_us")
+        ach = work / (live_us * 1e-6) / scale
+        row = dict(kernel=sym if len(rs) > 1 else rs[0]["kernel"], bound=rs[0]["bound"], achieved=round(ach, 2),
+                   peak=rs[0]["peak"], unit=rs[0]["unit"], frac=round(ach / rs[0]["peak"], 4),
+                   traffic=(round(sum(r["traffic"] * r["launches_per_step"] for r in rs) / n)
+                            if all(r.get("traffic") is not None for r in rs) else None),
+                   avg_kernel_us=round(live_us / n, 3), launches_per_step=n, us_per_step=round(step_us, 1),
+                   shapes=len(rs))
+        row[work_key] = round(work / n)
+        if all("in_step_us" in r for r in rs):
+            row["frac_in_step"] = round(work / (step_us * 1e-6) / scale / rs[0]["peak"], 4)
+        elif any(r.get("stale") for r in rs):
+            row["stale"] = True         # profiles/in_step_us.json was measured on other kernel sources
+        return row
+    ranked = sorted((pooled(k, v) for k, v in groups.items()), key=lambda r: -r["us_per_step"])
+    if not ranked:
+        return None, None
+    top = ranked[0]
+    other = next((r for r in ranked[1:] if r["bound"] != top["bound"]), None)
+    return top, other
+
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_in_step", "stale", "traffic",
+              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "avg_kernel_us", "avg_kernel_ms",
+              "launches_per_step", "us_per_step", "elements")
+
+
+def compact_line(out, detail_path):
+    """The ONE stdout line: the fields the driver's record needs, < 4 KB.  Everything else (roofline_kernels,
+    other_workloads, chains_per_gpu, timing, calibration, notes) is in the side file ``detail`` and on stderr."""
+    def pick(d, keys):
+        return None if d is None else {k: d[k] for k in keys if k in d}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out["config"]
+    line["config"] = {"workload": cfg["workload"][:300], "params": cfg["params"], "chains": cfg["chains"],
+                      "step_path": cfg["step_path"][:200]}
+    for k in ("ranks_seen", "backend"):
+        if k in out:
+            line[k] = out[k]
+    if "devices" in out:
+        line["devices"] = out["devices"][:8]
+    for k in ("roofline", "roofline_mfma", "roofline_hbm", "roofline_sampler", "roofline_flat_arena"):
+        if out.get(k) is not None:
+            line[k] = pick(out[k], _ROOF_KEYS)
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "host_cpus", "kind"))
+        line["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:160]
+        line["speedup_vs_cpu"] = out.get("speedup_vs_cpu")
+    if out.get("samples_per_sec"):
+        line["samples_per_sec"] = pick(out["samples_per_sec"], ("value", "per_chain", "leapfrog_steps_per_sample",
+                                                                "reject_samples"))
+    cg = out.get("chains_per_gpu")
+    if isinstance(cg, dict):
+        line["chains_per_gpu"] = {k: v["aggregate_steps_per_s"] for k, v in cg.items()
+                                  if isinstance(v, dict) and "aggregate_steps_per_s" in v}
+    if out.get("exchange"):
+        line["exchange"] = pick(out["exchange"], ("chains", "ensemble_ms", "gather_ms", "ensemble_matches_single_process",
+                                                  "gather_order_checked"))
+    if out.get("other_workloads"):
+        line["other_workloads"] = {k.split(" ", 1)[1][:48]: v.get("value", "error") for k, v in out["other_workloads"].items()}
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("other_workloads", "exchange", "chains_per_gpu", "devices"):      # (never needed at today's sizes)
+        if len(text) < 4096:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 4096, len(text)
+    return text
+
+
 def main():
     args = parse()
+    rc = self_launch(args)
+    if rc is not None:
+        raise SystemExit(rc)
     # stdout carries exactly ONE line, the JSON: whatever libraries print while the run is
     # going (RCCL announces its library path on stdout) is sent to stderr at the fd level
     sys.stdout.flush()
@@ -680,6 +819,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE = {world}: the launcher's --nproc-per-node and "
+                         "--gpus must agree")
     n_dev = torch.cuda.device_count()
     if local >= n_dev and args.backend != "gloo":
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {n_dev} GPU(s) visible (ranks may share a GPU only with "
@@ -752,8 +894,8 @@ def main():
     fused = runner._fused_dense() is not None
     source = runner._batches()
     path = ("fused dense step: mlp_fwdbwd + sampler(+slice-sum, prior) + finalize, 3 direct launches" if fused else
-            "eager" if args.eager else "hipGraph of autograd fwd/bwd (hand-written conv / BN kernels) + fused sampler; "
-            "minibatch gather (+ augmentation) + argument block + deferred bookkeeping in one launch between replays")
+            "eager" if args.eager else "hipGraph replay (hand-written conv / BN fwd+bwd kernels, fused sampler) + 1 "
+            "staging launch (minibatch gather, augmentation, argument block)")
 
     def full_batches():
         "the runner's own hot-loop batch stream, epoch after epoch, without the ragged last minibatch (N % 128)"
@@ -883,12 +1025,21 @@ def main():
             shutil.rmtree(tmp, ignore_errors=True)
     exchange = exchange_leg(model, rank, world, device, args.exchange_samples, cdev, args.backend) if distributed else None
 
+    ranks_seen, devices = 1, [{"rank": 0, "local_rank": local, "device": torch.cuda.get_device_name(device),
+                               "index": device.index}]
+    if distributed:
+        ranks_seen = dist.get_world_size()
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, {"rank": rank, "local_rank": local, "index": device.index,
+                                         "device": torch.cuda.get_device_name(device)})
     value = world * K / dt_block
     out = {
         "metric": f"leapfrog steps/sec, {args.inference}", "value": round(value, 2),
         "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(dt_block / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_seen": ranks_seen, "backend": ("nccl (RCCL)" if args.backend == "nccl" else "gloo") if distributed else None,
+        "devices": devices,
         "config": {"workload": f"{name} {args.inference} batch=128 N={N} (L={L} steps/epoch) "
                                f"lr={'1e-4' if hmc else '0.01'} cosine momentum={'1' if hmc else '0.994'} "
                                f"T={args.temperature:g} metrics_skip={args.metrics_skip} prior={prior}"
@@ -952,12 +1103,17 @@ def main():
                 bns = []
                 out["roofline_bn_error"] = f"{type(exc).__name__}: {exc}"
             rows_all_k = attach_in_step(convs + bns)
-            top = max(rows_all_k, key=lambda r: r.get("in_step_us", r["avg_kernel_us"]) * r["launches_per_step"])
-            out["roofline"] = dict(top, share_note="dominant kernel = largest (launches per step x in-step duration) over "
-                                                   "ALL rows of roofline_kernels (convolutions against the fp32-MFMA "
-                                                   "peak, BatchNorm kernels against HBM); achieved / frac from the live "
-                                                   "isolated launches, achieved_in_step / frac_in_step from the "
-                                                   "committed in-step durations")
+            # the headline row: the SYMBOL with the largest time per step (BatchNorm's backward is one symbol over
+            # three shapes), and beside it the largest symbol of the other roofline kind
+            top, other = headline_rooflines(rows_all_k)
+            out["roofline"] = top
+            if other is not None:
+                out["roofline_mfma" if other["bound"] == "mfma" else "roofline_hbm"] = other
+            out["roofline_note"] = ("roofline = the device symbol with the largest (launches per step x duration), its shapes "
+                                    "pooled; achieved / frac from live isolated launches (HIP events in the dispatch packet), "
+                                    "frac_in_step from profiles/in_step_us.json when its source_sha matches this tree "
+                                    "(else stale: true and no in-step figure); traffic from profiles/pmc_traffic.json "
+                                    "under the same rule")
             out["roofline_kernels"] = rows_all_k
             if sampler_line:
                 out["roofline_sampler"] = sampler_line
@@ -1004,8 +1160,20 @@ def main():
                           "(oracle/: reference-op-order torch-CPU loop on oracle/nets.py's plain-torch restatement of "
                           "the net, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        from bnn_priors_amd import _hip
+        out["source_sha"] = _hip.source_sha()
+        detail_path = args.detail or None
+        if detail_path:
+            try:
+                with open(detail_path, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as exc:
+                print(f"bench.py: cannot write {detail_path}: {exc}", file=sys.stderr)
+                detail_path = None
+        print(json.dumps(out), file=sys.stderr)        # the full record, for logs
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (compact_line(out, detail_path) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

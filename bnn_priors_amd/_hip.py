@@ -374,6 +374,21 @@ def check(err, what):
         raise RuntimeError(f"{what} failed: hipError {err} ({lib().sgmcmc_error_string(err).decode()})")
 
 
+def source_sha():
+    """Hash of every kernel / ABI source (csrc/*, include/*): what a committed measurement of the kernels
+    (profiles/in_step_us.json, profiles/pmc_traffic.json) records as ``source_sha`` and bench.py compares with,
+    so that figures measured on other kernels than the tree's are marked stale instead of being mixed in."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(_HERE, "csrc"), INCLUDE_DIR):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".inc", ".h", ".hpp")):
+                h.update(name.encode())
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose=False):
     """hipcc cross-compile for gfx950 (works without a GPU)."""
     import subprocess

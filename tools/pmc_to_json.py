@@ -4,8 +4,12 @@ lists in `roofline_kernels`, keyed by bench.py's row names.  bench.py cannot col
 rocprofv3 wrapper and their own pass); it copies these per-launch figures into `roofline.traffic` and names this file
 as the source.  `python tools/pmc_to_json.py profiles/r04_conv_kernels_pmc_hbm.txt profiles/r04_bn_16x32_pmc_hbm.txt ... > profiles/pmc_traffic.json`"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bnn_priors_amd import _hip  # noqa: E402
 
 rows = {}
 for path in sys.argv[1:]:
@@ -36,7 +40,7 @@ for path in sys.argv[1:]:
         if ratio:
             rows[key]["algorithmic_bytes"] = round((float(ratio.group(1)) + float(ratio.group(2))) * 1e6)
             rows[key]["traffic_over_algorithmic"] = float(ratio.group(3))
-print(json.dumps({"source": ", ".join(sys.argv[1:]),
-                  "collected_by": "tools/r04_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter-only passes "
+print(json.dumps({"source": ", ".join(sys.argv[1:]), "source_sha": _hip.source_sha(),
+                  "collected_by": "tools/pmc_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter-only passes "
                                   "with --kernel-trace) over tools/conv_pmc.py and tools/bn_pmc.py at n = 128",
                   "kernels": rows}, indent=1))
