@@ -634,7 +634,7 @@ def exchange_leg(model, rank, world, device, E, cdev=None, backend="nccl", n_tes
     return out
 
 
-def other_workloads(args):
+def other_workloads(args, only=None):
     """BASELINE configs[1], [2] and [4] as sub-runs of this script (fresh processes: their own captured graphs and
     kernel tables), so that the ONE line the driver records carries all four GPU configurations.  Each sub-run times
     its leapfrog loop exactly as the headline does and K = 10 full sample cycles; no rooflines, no CPU baseline."""
@@ -649,23 +649,30 @@ def other_workloads(args):
         "configs[4] googleresnet HMCReject L=50 T=0.01 student-t": ["--inference", "HMCReject", "--trajectory", "50",
                                                                    "--temperature", "0.01"],
     }
+    import tempfile
     out = {}
     for name, flags in subs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "100", "--warmup", "20",
-               "--cpu-budget", "0", "--sweep-log2", "0", "--no-kernel-timing", "--stream-chains", "", "--samples", "10",
-               "--other-workloads", "0", "--eval-rows", "0", "--metrics-skip", str(args.metrics_skip)] + flags
-        t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
-                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-            line = json.loads(r.stdout.strip().splitlines()[-1])
-            sps = line.get("samples_per_sec") or {}
-            out[name] = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
-                         "samples_per_sec": sps.get("value"), "leapfrog_steps_per_sample": sps.get("leapfrog_steps_per_sample"),
-                         "workload": line["config"]["workload"], "step_path": line["config"]["step_path"],
-                         "timed_steps": line["timing"]["timed_steps"], "sub_run_s": round(time.perf_counter() - t0, 1)}
-        except Exception as exc:      # a sub-run never takes the headline down
-            out[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+        if only is not None and only not in name:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".json", prefix="bench_sub_") as side:
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "100", "--warmup", "20",
+                   "--cpu-budget", "0", "--sweep-log2", "0", "--no-kernel-timing", "--stream-chains", "", "--samples", "10",
+                   "--other-workloads", "0", "--eval-rows", "0", "--metrics-skip", str(args.metrics_skip),
+                   "--detail", side.name] + flags
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                json.loads(r.stdout.strip().splitlines()[-1])           # (the sub-run's own compact line parses)
+                with open(side.name) as f:
+                    line = json.load(f)                                 # ... and its full record is the side file
+                sps = line.get("samples_per_sec") or {}
+                out[name] = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                             "samples_per_sec": sps.get("value"), "leapfrog_steps_per_sample": sps.get("leapfrog_steps_per_sample"),
+                             "workload": line["config"]["workload"], "step_path": line["config"]["step_path"],
+                             "timed_steps": line["timing"]["timed_steps"], "sub_run_s": round(time.perf_counter() - t0, 1)}
+            except Exception as exc:      # a sub-run never takes the headline down
+                out[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
     return out
 
 

@@ -163,13 +163,7 @@ def _row_groups(dataloader, device, rows):
         torch.empty((), dtype=torch.int64).random_(generator=dataloader.generator)
         bs = dataloader.batch_size
         per = max(bs, rows // bs * bs)
-        key = (res[0].data_ptr(), res[1].data_ptr(), str(device))
-        cached = _resident_cache.get(id(dataloader))
-        if cached is None or cached[0] != key:
-            cached = _resident_cache[id(dataloader)] = (key, res[0].to(device), res[1].to(device))
-            if len(_resident_cache) > 8:
-                _resident_cache.pop(next(iter(_resident_cache)))
-        x, y = cached[1], cached[2]
+        x, y = _resident_on(dataloader, res, device)
         for i in range(0, x.shape[0], per):
             yield x[i:i + per], y[i:i + per]
         return
@@ -185,7 +179,32 @@ def _row_groups(dataloader, device, rows):
         yield (torch.cat(xs), torch.cat(ys)) if len(xs) > 1 else (xs[0], ys[0])
 
 
-_resident_cache = {}        # id(loader) -> (key, x on the device, y on the device): host-resident test sets are moved once
+# loader -> (host x, host y, their versions, device, x on the device, y on the device): a host-resident test set is moved
+# once per loader.  Weakly keyed by the loader OBJECT (an id() can be reused by the next loader of a loop that builds
+# fresh ones) and holding the host tensors it was copied from, so neither their address nor the loader's can come
+# back meaning other data; an in-place edit of the host tensors (normalisation after a first evaluation) bumps their
+# version counters and invalidates the copy.  Tensors already on the device are never cached (nothing is copied).
+_resident_cache = weakref.WeakKeyDictionary()
+
+
+def _root(t):
+    "the tensor a view was sliced from (views share its version counter), else the tensor itself"
+    return t._base if t._base is not None else t
+
+
+def _resident_on(dataloader, res, device):
+    x, y = res
+    device = torch.device(device)
+    if x.device == device and y.device == device:
+        return x, y
+    c = _resident_cache.get(dataloader)
+    if (c is not None and c[0] is _root(x) and c[1] is _root(y)
+            and c[2] == (x._version, y._version, tuple(x.shape), tuple(y.shape)) and c[3] == device):
+        return c[4], c[5]
+    xd, yd = x.to(device), y.to(device)
+    _resident_cache[dataloader] = (_root(x), _root(y), (x._version, y._version, tuple(x.shape), tuple(y.shape)),
+                                   device, xd, yd)
+    return xd, yd
 
 
 class _GraphedLogits:

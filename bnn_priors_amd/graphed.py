@@ -340,7 +340,12 @@ class GraphedAccumulate:
             self.loss, self.grads = share.loss, share.grads
         self.x.copy_(rep(x_example))
         self.y.copy_(rep(y_example))
-        buffers = {k: v.clone() for k, v in self.model.state_dict().items()}
+        # What the warm-up runs and the capture can change is put back afterwards.  In log mode (a lane of
+        # ConcurrentAccumulate -- possibly built in the MIDDLE of a pass, with other lanes' replays in flight) that is
+        # only the shared accumulators: the bodies neither advance the running statistics nor the batch counters nor
+        # touch a parameter, so nothing of the model is snapshotted or written back (a restore would race with the
+        # other lanes' reads and could put stale running statistics over ones a log replay has advanced since).
+        buffers = ({k: v.clone() for k, v in self.model.state_dict().items()} if log_slots is None else {})
         keep = ([g.clone() for g in self.grads], self.loss.clone()) if share is not None else None
         if share is None:
             self.begin()
@@ -355,7 +360,7 @@ class GraphedAccumulate:
         with _capture.capture(self.graph):
             self._body()
         with torch.no_grad():
-            for k, v in self.model.state_dict().items():
+            for k, v in (self.model.state_dict().items() if buffers else ()):
                 v.copy_(buffers[k])
             if keep is not None:        # (the warm-up runs added to accumulators that are somebody else's)
                 for g, k in zip(self.grads, keep[0]):
@@ -431,6 +436,8 @@ EXACT_GROUP = EXACT_GROUP if EXACT_GROUP == "auto" else int(EXACT_GROUP)
 def pick_group(n_full, rows, lanes, want=None):
     "minibatches per replay for a pass of ``n_full`` full-size minibatches of ``rows`` rows on ``lanes`` streams"
     want = EXACT_GROUP if want is None else want
+    if n_full is None:        # a source that cannot announce its full-size minibatches is never run in groups (run()):
+        return 1              # no grouped bodies are captured for it -- their HBM and capture time would be spent unused
     cap = max(1, 1024 // max(rows, 1))            # (the fused head + loss launch takes up to 1,024 rows)
     if want != "auto":
         return max(1, min(int(want), cap))
@@ -528,6 +535,12 @@ class ConcurrentAccumulate:
         G, n_lanes = self.group, len(self.streams)
         n_full = batches.n_full_batches() if hasattr(batches, "n_full_batches") else None
         n_groups = n_full // G if (G > 1 and n_full is not None) else 0
+        if n_groups and hasattr(batches, "example"):
+            # a later pass over minibatches of ANOTHER size than the bodies were captured for (the cached accumulator of
+            # potential.exact): no groups -- every minibatch goes through the one-minibatch / off-shape / eager route below
+            ex = batches.example()
+            if ex is None or not self.lanes[0].matches(*ex):
+                n_groups = 0
         target = {"dst": None, "grp": None}
         try:       # (a source that can gather a whole group with one launch: inference._BatchSource)
             filling = batches.filling(lambda rows: target["dst"](rows) if target["dst"] else None,
@@ -551,8 +564,9 @@ class ConcurrentAccumulate:
                         x, y = next(it)
                         target["grp"] = None
                         if not lane.matches(x, y):      # (the contract of n_full_batches: the FIRST n_full ones are full)
-                            raise RuntimeError("a batch source that announces its full-size minibatches must yield them "
-                                               f"first: got {tuple(x.shape)} inside a group of {lane.shape[0]}")
+                            raise RuntimeError("a batch source that announces n_full_batches() full-size minibatches must "
+                                               f"yield them first: got {tuple(x.shape)} inside a group of {lane.shape[0]} "
+                                               "(sources of another minibatch size are detected through example())")
                         if not lane.owns(x, y, j):
                             xs, ys = lane.slot(j)
                             stage_batch(xs, x, ys, y)

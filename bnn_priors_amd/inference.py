@@ -99,7 +99,11 @@ class LazyBatch:
 
     def stageable(self, x_dst, y_dst):
         s = self.src
+        # (gather_stage_kernel reads rows as data[idx[i]] / labels[idx[i]] with unit strides, everything on ONE device)
+        dev = s.x.device
         return (s.x.dtype == torch.float32 and s.x.is_contiguous() and s.y.dtype == torch.int64 and s.y.dim() == 1
+                and s.y.is_contiguous() and self.idx.is_contiguous() and self.idx.dtype == torch.int64
+                and s.y.device == dev and self.idx.device == dev and x_dst.device == dev and y_dst.device == dev
                 and x_dst.dtype == torch.float32 and y_dst.dtype == torch.int64 and x_dst.is_contiguous()
                 and y_dst.is_contiguous() and (tuple(x_dst.shape), tuple(y_dst.shape)) == self.shapes)
 
@@ -115,8 +119,10 @@ class LazyBatch:
             pad, flip, seed, strm = aug.pad, int(aug.flip), aug.seed & (2 ** 64 - 1), aug.stream
             fill = 0
             if aug.fill is not None:
-                if aug.fill.device != s.x.device:
-                    aug.fill = aug.fill.to(s.x.device)
+                if aug.fill.numel() != c:          # (as RandomCropFlip.gather checks: one fill value per channel)
+                    raise ValueError(f"RandomCropFlip.fill has {aug.fill.numel()} values for {c} channels")
+                if aug.fill.device != s.x.device or aug.fill.dtype != torch.float32 or not aug.fill.is_contiguous():
+                    aug.fill = aug.fill.to(device=s.x.device, dtype=torch.float32).contiguous()
                 fill = aug.fill.data_ptr()
         else:
             row = 1
@@ -160,6 +166,10 @@ class _BatchSource:
             self.x, self.y = (t.to(device) for t in ds.tensors)
             if self.augment is not None:
                 self.x = self.x.contiguous()
+            if self.y.dim() == 1 and not self.y.is_contiguous():
+                # a label column of a wider table (a strided view that .to(device) keeps as it is): the staging kernel
+                # reads labels with unit stride, so the source owns a packed copy
+                self.y = self.y.contiguous()
 
     def __len__(self):
         return len(self.dl)

@@ -146,3 +146,13 @@ def test_one_gpu_line_carries_roofline_and_names_its_detail_file(tmp_path):
     assert 0 < line["roofline_sampler"]["frac"] <= 1 and 0 < line["roofline_flat_arena"]["frac"] <= 1
     full = json.loads(detail.read_text())
     assert len(full["roofline_kernels"]) >= 18 and full["source_sha"]
+    assert "other_workloads" not in line
+
+
+@pytest.mark.gpu
+def test_a_sub_run_of_other_workloads_is_read_from_its_side_file():
+    import types
+    got = bench.other_workloads(types.SimpleNamespace(metrics_skip=10), only="densenet")
+    (name, row), = got.items()
+    assert "error" not in row, row
+    assert row["value"] > 0 and row["timed_steps"] > 0 and "dense" in row["step_path"]

@@ -157,3 +157,45 @@ def test_eval_batchnorm_in_the_convolution_epilogue_changes_no_bit(n, monkeypatc
     with torch.no_grad():
         want = ref.net(x.double())
     torch.testing.assert_close(fused.double(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_resident_copy_of_a_host_test_set_follows_the_loader_object_and_its_data():
+    """the device copy of a host-resident test set is cached per loader OBJECT (weakly) and invalidated by
+    in-place edits of the host tensors -- never by id() / data_ptr() alone, which a later loader can reuse."""
+    import gc
+    import torch
+    from bnn_priors_amd import evaluation as ev
+
+    def groups(loader):
+        return [(x.clone(), y.clone()) for x, y in ev._row_groups(loader, "cpu", 1024)]
+
+    class _Fake(str):          # a device that is not the tensors': forces the copy branch on a CPU-only box
+        pass
+    x, y = torch.arange(20.).view(10, 2), torch.arange(10)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=4)
+    # (on one device nothing is copied and nothing cached)
+    assert torch.equal(groups(loader)[0][0], x) and len(ev._resident_cache) == 0
+    calls = []
+    real_to = torch.Tensor.to
+
+    def counting_to(self, *a, **k):
+        calls.append(1)
+        return real_to(self, "cpu").clone()
+    dev = torch.device("meta")          # stands in for "another device": _resident_on only compares and calls .to()
+    torch.Tensor.to = counting_to
+    try:
+        a1 = ev._resident_on(loader, (x[:10], y[:10]), dev)
+        a2 = ev._resident_on(loader, (x[:10], y[:10]), dev)
+        assert a1[0] is a2[0] and len(calls) == 2                    # second call: the cached copy
+        x.mul_(2)                                                    # in-place edit of the host tensor
+        a3 = ev._resident_on(loader, (x[:10], y[:10]), dev)
+        assert a3[0] is not a1[0] and torch.equal(a3[0], x) and len(calls) == 4
+        loader2 = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x.clone(), y.clone()), batch_size=4)
+        b = ev._resident_on(loader2, (loader2.dataset.tensors[0][:10], loader2.dataset.tensors[1][:10]), dev)
+        assert b[0] is not a3[0] and len(ev._resident_cache) == 2
+        del loader2, b
+        gc.collect()
+        assert len(ev._resident_cache) == 1                          # the entry went with its loader
+    finally:
+        torch.Tensor.to = real_to
+        ev._resident_cache.clear()

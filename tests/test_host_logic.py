@@ -13,7 +13,7 @@ def test_group_size_leaves_the_fewest_leftovers_and_deals_groups_evenly():
     assert graphed.pick_group(4, 32, 3, "auto") == 4               # one group
     assert graphed.pick_group(390, 256, 3, "auto") == 4            # 1,024 rows per launch at most (the fused head)
     assert graphed.pick_group(390, 128, 3, 16) == 8 and graphed.pick_group(390, 128, 3, 1) == 1
-    assert graphed.pick_group(None, 128, 3, "auto") == 4
+    assert graphed.pick_group(None, 128, 3, "auto") == 1             # unknown pass length: never grouped
 
 
 def _source(shuffle, n=300):
