@@ -7,9 +7,14 @@ engines' SQs.  A v_mfma_f32_16x16x4_f32 occupies its SIMD's matrix pipe for 32 c
     mfma_busy_expected = 32 * N_mfma            N_mfma = flop / 2048   (16 x 16 x 4 x 2 flop per wave-instruction)
     pipe utilisation   = mfma_busy / (1024 SIMDs x kernel duration x clock)
 
-The clock is not exported: GRBM_GUI_ACTIVE (cycles the GPU was active during the dispatch; under counter collection
-dispatches are serialised, so it includes the launch's own ramp) stands in for duration x clock.  `algorithmic` is
-flop / duration / 157.3 TF from the pass's own kernel trace, for reconciliation with bench.py's roofline rows."""
+The clock is not exported (GRBM_GUI_ACTIVE as collected here is summed over the XCDs and covers more than the
+dispatch), so `pipe` uses the dispatch duration of the pass's own kernel trace at the nominal 2.4 GHz; it equals
+`algor.` = flop / duration / 157.3 TF by construction when busy/exp = 1 -- which is the reconciliation: the counter
+counts exactly 32 cycles per v_mfma_f32_16x16x4_f32, and the fraction of peak is the algorithmic one (the round-3
+`MfmaUtil` file, normalised by rocprofiler's gfx94x formula, was below it and is retired).
+`wave us` = SQ_WAVE_CYCLES x 4 / SQ_WAVES at 2.4 GHz: the mean lifetime of a wave; `mfma us` = the time the two waves
+that share a SIMD need for their MFMAs at the pipe's rate (2 x N_mfma_per_wave x 32 cycles): what is left of `wave us`
+is spent with no MFMA issued on that SIMD unless the co-resident workgroup is out of phase."""
 import collections
 import csv
 import re
@@ -51,9 +56,9 @@ def flops(kname):
 
 print(__doc__.split("\n\n")[1])
 print()
-hdr = ("kernel", "us", "algor.", "pipe", "busy/exp", "parked", "issue-st", "of it LDS", "active", "LDS act", "VALU act",
+hdr = ("kernel", "us", "algor.", "pipe", "busy/exp", "wave us", "mfma us", "parked", "issue-st", "of it LDS", "active", "LDS act", "VALU act",
        "VMEM act", "LDS ins/MFMA", "bank conf")
-print("%-52s %6s %6s %6s %8s %7s %8s %9s %7s %8s %8s %8s %12s %9s" % hdr)
+print("%-52s %6s %6s %6s %8s %7s %7s %7s %8s %9s %7s %8s %8s %8s %12s %9s" % hdr)
 for k in sorted(val, key=lambda k: -mean(val[k].get("SQ_WAVE_CYCLES", [0]))):
     f = flops(k)
     if f is None:
@@ -65,15 +70,20 @@ for k in sorted(val, key=lambda k: -mean(val[k].get("SQ_WAVE_CYCLES", [0]))):
     busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     gui = v.get("GRBM_GUI_ACTIVE", 0.0) or 1.0
     short = re.sub(r"void conv::|\(.*", "", k)
-    print("%-52s %6.2f %6.3f %6.3f %8.3f %6.1f%% %7.1f%% %8.1f%% %6.1f%% %7.1f%% %7.1f%% %7.1f%% %12.2f %8.1f%%" % (
-        short[:52], us, f / (us * 1e-6) / 157.3e12 if us else 0, busy / (1024.0 * gui), busy / (32.0 * n_mfma),
+    waves = v.get("SQ_WAVES", 0.0) or 1.0
+    wave_us = wc * 4.0 / waves / 2400.0
+    resident = 2.0 if "bwd" not in short and True else 2.0
+    mfma_us = resident * (n_mfma / waves) * 32.0 / 2400.0
+    print("%-52s %6.2f %6.3f %6.3f %8.3f %7.2f %7.2f %6.1f%% %7.1f%% %8.1f%% %6.1f%% %7.1f%% %7.1f%% %7.1f%% %12.2f %8.1f%%" % (
+        short[:52], us, f / (us * 1e-6) / 157.3e12 if us else 0, busy / (1024.0 * us * 2400.0) if us else 0, busy / (32.0 * n_mfma),
+        wave_us, mfma_us,
         100 * v.get("SQ_WAIT_ANY", 0) / wc, 100 * v.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * v.get("SQ_WAIT_INST_LDS", 0) / wc,
         100 * v.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100 * v.get("SQ_ACTIVE_INST_LDS", 0) / wc,
         100 * v.get("SQ_ACTIVE_INST_VALU", 0) / wc, 100 * v.get("SQ_ACTIVE_INST_VMEM", 0) / wc,
         v.get("SQ_INSTS_LDS", 0) / n_mfma, 100 * v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0), 1.0)))
 print()
 print("columns: us = mean dispatch duration in the first pass's kernel trace (serialised by the profiler); algor. = flop / us / "
-      "157.3 TF; pipe = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE); busy/exp = SQ_VALU_MFMA_BUSY_CYCLES / (32 x N_mfma) "
+      "157.3 TF; pipe = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x us x 2.4 GHz); busy/exp = SQ_VALU_MFMA_BUSY_CYCLES / (32 x N_mfma) "
       "(1.0 = the counter counts what the arithmetic says); parked = SQ_WAIT_ANY (s_waitcnt / barrier), issue-st = "
       "SQ_WAIT_INST_ANY, active = SQ_ACTIVE_INST_ANY, each as a share of SQ_WAVE_CYCLES; LDS ins/MFMA = SQ_INSTS_LDS per "
       "wave-MFMA; bank conf = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE")
