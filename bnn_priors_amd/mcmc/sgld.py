@@ -196,7 +196,8 @@ class SGLD(torch.optim.Optimizer):
         from the priors, so ``add_prior_gradient`` gives it a zeroed ``.grad`` to accumulate into."""
         from ..prior import named_priors
         eng = self._engine
-        by_param = {id(pr.p): pr for _, pr in named_priors(model)}
+        # (a mixture's components share its tensor and own no density: prior/mixture.py)
+        by_param = {id(pr.p): pr for _, pr in named_priors(model) if not getattr(pr, "is_component", False)}
         priors = [by_param.pop(id(p), None) for p in eng.params]
         specs = [pr.fused_spec() if pr is not None else None for pr in priors]
         links = [None] * len(specs)

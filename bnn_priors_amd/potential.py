@@ -16,6 +16,7 @@ ATen launches and two validation syncs per prior tensor per step).  Here
 Nothing here synchronises with the host; callers ``.item()`` what they log.
 """
 import itertools
+import warnings
 
 import torch
 
@@ -25,6 +26,9 @@ from . import pool as _pool
 from .models.base import ClassificationModel
 
 
+_noticed = set()       # prior-class sets whose autograd route has been announced (once per process)
+
+
 class Potential:
     def __init__(self, model, optimizer, num_data):
         self.model, self.opt, self.N = model, optimizer, float(num_data)
@@ -32,6 +36,13 @@ class Potential:
                      and isinstance(model.softmax_temp, (int, float))
                      and hasattr(optimizer, "fuse_priors"))
         self.leftover = optimizer.fuse_priors(model) if self.fast else None
+        if self.leftover:
+            kinds = tuple(sorted({type(pr).__name__ for pr in self.leftover}))
+            if kinds not in _noticed:
+                _noticed.add(kinds)
+                warnings.warn(f"priors {', '.join(kinds)} are not element-wise families of the HIP prior hook: their "
+                              "log-density is differentiated by autograd in every gradient evaluation and the step is not "
+                              "captured into a hipGraph (INTEGRATION.md section 1)", stacklevel=3)
 
     # ------------------------------------------------------------------ pieces
     def _logits(self, x):

@@ -49,7 +49,9 @@ class Uniform(Prior):
         return lp.sum() * (self.p.numel() / lp.numel())
 
     def fused_spec(self):
-        if not (_plain(self.low) and _plain(self.high)):
+        # (the hook knows this family as a hyper-prior: one element, evaluated in double; a whole tensor with a
+        #  uniform prior -- get_prior("uniform") -- stays in autograd)
+        if not (_plain(self.low) and _plain(self.high)) or self.p.numel() != 1:
             return None
         return self.fused_kind, float(self.low), float(self.high), 0.0
 

@@ -173,3 +173,102 @@ def test_fused_prior_hook_matches_reference_fixtures(golden_dir):
                                                              abs=1e-4 if dtype == torch.float32 else 1e-10), key
     assert {"gaussian", "laplace", "student-t", "cauchy", "gennorm", "gaussian_gamma", "laplace_gamma",
             "student-t_gamma", "gaussian_uniform", "laplace_uniform", "student-t_uniform", "horseshoe"} <= seen
+
+
+# ------------------------------------------------------------------ priors built by name and left to autograd (round 5)
+def _by_name_cases(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "priors_by_name.npz"))
+    return z, sorted({k.rsplit("|", 1)[0] for k in z.files})
+
+
+def _build_by_name(key, z):
+    import json
+    name, a, b, extra, shape, dt = key.split("|")
+    dtype = torch.float32 if dt == "float32" else torch.float64
+    kw = {k: json.loads(v) for k, v in (item.split("=", 1) for item in filter(None, extra.split(";")))}
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        torch.manual_seed(0)
+        pr = P.get_prior(name)(tuple(int(s) for s in shape.split("x")), float(a), float(b), **kw)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        pr.p.copy_(torch.from_numpy(z[key + "|theta"]).to(dtype))
+        if key + "|weights" in z.files:
+            pr.mixture_weights.copy_(torch.from_numpy(z[key + "|weights"]).to(dtype))
+    return name, pr, dtype
+
+
+def test_priors_by_name_match_reference_fixtures(golden_dir):
+    """``get_prior("lognormal" | "uniform" | "mixture" | "scale_mixture")`` builds the reference's prior (its table:
+    prior/mixture.py:17-50) instead of raising: the model-level log-prior, its gradient w.r.t. the tensor and the
+    mixture logits, the transformed value and the state_dict's keys against values captured from the imported reference
+    (tests/golden/make_prior_by_name_goldens.py).  None of them is handed to the HIP hook (fused_spec() is None)."""
+    import json
+    z, keys = _by_name_cases(golden_dir)
+    assert len(keys) == 40 and {k.split("|")[0] for k in keys} == {"lognormal", "uniform", "mixture", "scale_mixture"}
+    for key in keys:
+        name, pr, dtype = _build_by_name(key, z)
+        tol = dict(rel=2e-5, abs=2e-5) if dtype == torch.float32 else dict(rel=1e-11, abs=1e-11)
+        assert pr.fused_spec() is None, key
+        assert sorted(pr.state_dict().keys()) == json.loads(str(z[key + "|state_keys"])), key
+        assert len(list(pr.parameters())) == int(z[key + "|n_parameters"]), key
+        total = sum(m.log_prob() for _, m in P.named_priors(pr))
+        assert float(total) == pytest.approx(float(z[key + "|log_prior"]), **tol), key
+        if isinstance(total, torch.Tensor) and total.requires_grad:
+            total.backward()
+        got = pr.p.grad if pr.p.grad is not None else torch.zeros_like(pr.p)
+        torch.testing.assert_close(got.double(), torch.from_numpy(z[key + "|grad_theta"]), rtol=tol["rel"] * 5, atol=tol["abs"])
+        torch.testing.assert_close(pr().detach().double(), torch.from_numpy(z[key + "|value"]), rtol=tol["rel"], atol=tol["abs"])
+        if key + "|grad_weights" in z.files:
+            torch.testing.assert_close(pr.mixture_weights.grad.double(), torch.from_numpy(z[key + "|grad_weights"]),
+                                       rtol=tol["rel"] * 5, atol=tol["abs"])
+
+
+def test_a_mixtures_components_are_views_not_priors_of_their_own():
+    torch.manual_seed(3)
+    m = P.get_prior("mixture")((6, 2), 0.0, 0.5, components="g_l_s")
+    assert [n for n, _ in m.named_parameters()] == ["p", "mixture_weights"]          # one tensor, one logit vector
+    assert all(c.p is m.p and c.log_prob() == 0. and c.fused_spec() is None and c.is_component for c in m.components)
+    with pytest.raises(KeyError):
+        P.get_prior("convcorrnormal")          # out of scope stays an error, with the table in the message
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lognormal", "uniform", "mixture", "scale_mixture"])
+def test_by_name_priors_run_through_the_sampler_as_leftover(name):
+    """a dense classifier whose WEIGHT prior is one of the by-name families: the optimizer leaves exactly those priors
+    to autograd (the bias priors stay in the HIP hook), announces it once, and the gradient of the average potential
+    equals the reference formulation's (models/base.py:72-77 through autograd) -- then one sampler transition runs"""
+    import copy
+    import warnings
+    from bnn_priors_amd import mcmc, models, potential
+    dev, N = "cuda:0", 512.0
+    torch.manual_seed(0)
+    x, y = torch.rand(64, 784), torch.randint(0, 10, (64,))
+    net = models.get_model(x, y, "classificationdensenet", width=16, depth=3, weight_prior=name, weight_loc=0.,
+                           weight_scale=2 ** .5 if name != "uniform" else 1.0, bias_prior="gaussian", bias_scale=1.).to(dev)
+    x, y = x.to(dev), y.to(dev)
+    ref = copy.deepcopy(net)
+    opt = mcmc.VerletSGLD(net.parameters(), lr=1e-4, num_data=N, momentum=0.9, temperature=1.0, seed=3)
+    potential._noticed.clear()
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        pot = potential.Potential(net, opt, N)
+        potential.Potential(net, opt, N)
+    assert sum("differentiated by autograd" in str(w.message) for w in seen) == 1      # one notice per family set
+    want_left = {id(pr) for n_, pr in P.named_priors(net) if "weight_prior" in n_ and not getattr(pr, "is_component", False)}
+    assert {id(pr) for pr in pot.leftover} == want_left and pot.fast
+    loss, log_prior, pot_value, acc = pot.minibatch(x, y, True)
+    _, lp_ref, potential_ref, _, _ = ref.split_potential_and_acc(x, y, N)
+    potential_ref.backward()
+    assert float(log_prior) == pytest.approx(float(lp_ref), rel=2e-5, abs=1e-3)
+    assert float(pot_value) == pytest.approx(float(potential_ref), rel=2e-5, abs=1e-5)
+    for (n_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        want = q.grad if q.grad is not None else torch.zeros_like(q)
+        torch.testing.assert_close(p.grad, want, rtol=2e-4, atol=2e-6, msg=lambda m: f"{name} {n_}: {m}")
+    opt.sample_momentum()
+    opt.initial_step(save_state=False)
+    assert all(torch.isfinite(p).all() for p in net.parameters())
