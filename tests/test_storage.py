@@ -3,6 +3,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -222,3 +223,16 @@ def test_a_device_state_dict_reaches_the_host_in_one_copy_per_dtype_with_the_sam
     for k, v in sd.items():
         assert not host[k].is_cuda and host[k].dtype == v.dtype and host[k].shape == v.shape
         assert torch.equal(host[k], v.cpu()), k
+
+
+@pytest.mark.skipif(H5DUMP is None, reason="h5dump / h5ls not installed (conda's hdf5 package has them in the build container)")
+def test_store_read_back_by_the_hdf5_tools():
+    """files written through _h5.py read back by a reader that is not _h5.py (h5ls / h5dump): every dataset's name, type,
+    extent, chunking, fletcher32 filter, fill value and VALUES -- tests/golden/h5_independent_read.py, whose output is
+    committed as tests/golden/h5_independent_read.txt"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import h5_independent_read as H
+    text = H.main()
+    assert text.count("values equal") == 10 and "agree with what was stored" in text
+    committed = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5_independent_read.txt")).read()
+    assert [ln for ln in committed.splitlines() if "values equal" in ln] == [ln for ln in text.splitlines() if "values equal" in ln]
