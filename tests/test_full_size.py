@@ -158,3 +158,72 @@ def test_exact_pass_on_two_streams_and_in_groups_matches_the_sequential_pass(mod
                     assert torch.equal(b1[k], b2[k]), (k, lanes, group)
     if buffers:      # the statistics did advance (8 minibatches per pass)
         assert any(not torch.equal(results[0][0][3][k], buffers[k]) for k in buffers)
+
+
+
+def test_default_exact_pass_is_as_close_to_float64_as_float32_library_kernels_are():
+    """VERDICT r4, parity hole: the DEFAULT exact pass (3 lanes x G minibatches per launch on the persistent
+    convolutions) at googleresnet / batch 128 against a FLOAT64 autograd evaluation of the same quantity at the same
+    parameters (inference_reject.py:18-33; the same modules cast to double run on the library's double kernels --
+    every kernel of this package declines float64), after 200 leapfrog steps of the runner.
+
+    The condition-number argument (tools/conditioning_probe.py, gpurun r05_second/conditioning.txt): at this net float32
+    ITSELF is 1.4e-4 .. 1.8e-3 of the gradient's maximum away from the float64 value at every point probed (initialisation,
+    50 .. 800 steps) -- torch's own float32 kernels, one minibatch at a time -- because training-mode BatchNorm divides by
+    batch standard deviations of rounded activations 20 layers deep.  A bound of 1e-4 is therefore below what ANY float32
+    evaluation delivers here; the statement that can be made, and is asserted, is that the product's pass is as close
+    to the truth as the float32 library evaluation is (factor 2), and within 5e-3 absolutely, with the loss to 1e-6.
+    This replaces the 2e-2-of-maximum sanity bound between kernel generations above as the full-size accuracy
+    statement."""
+    import copy
+    from bnn_priors_amd import evaluation
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(21)
+    n = 8 * 128
+    x = torch.randn((n, 3, 32, 32), generator=g).to(dev)
+    y = torch.randint(0, 10, (n,), generator=g).to(dev)
+    train = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=128, shuffle=False)
+    test = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:128], y[:128]), batch_size=128)
+    model = RC.make_net(models, x[:2].cpu(), torch.tensor([0, 9]), device=dev, cfg=dict(model="googleresnet"))
+    torch.manual_seed(RC.SEED)
+    runner = inference_reject.VerletSGLDRunnerReject(
+        model=model, dataloader=train, dataloader_test=test, learning_rate=0.01, temperature=1.0, momentum=0.994,
+        reject_samples=True, metrics_saver=MemoryMetrics(), model_saver=None, seed=RC.SEED, chain_id=0,
+        cycle_seed=RC.CYCLE_SEED, use_graph=True, epochs_per_cycle=50, warmup_epochs=45, sample_epochs=5, skip=1,
+        metrics_skip=10, cycles=60, precond_update=1, sampling_decay="cosine")
+    step, done = runner.begin(), 0
+    while done < 200:
+        for xb, yb in runner._hot_batches():
+            if done >= 200:
+                break
+            step, done = step + 1, done + 1
+            runner.leapfrog(step, xb, yb, last_of_epoch=False)
+    runner._drain_rows()
+    runner._check_finite()
+    pot, batches = runner._potential(), list(train)
+
+    def autograd_reference(dtype):
+        ref = copy.deepcopy(model).to(dtype)
+        ref.train()
+        ref.zero_grad()
+        (ref.log_prior() / -pot.N).backward()
+        loss = 0.0
+        for xb, yb in batches:
+            this = ref.log_likelihood(xb.to(dtype), yb, -xb.size(0) / pot.N)
+            this.backward()
+            loss += float(this.detach())
+        return torch.cat([p.grad.double().flatten() for p in ref.parameters()]), loss
+
+    g64, l64 = autograd_reference(torch.float64)
+    with evaluation._plain_torch_layers():                    # float32 on the LIBRARY's kernels: the yard-stick
+        g32, l32 = autograd_reference(torch.float32)
+    loss, _, _ = pot.exact(runner._batches())
+    torch.cuda.synchronize()
+    from bnn_priors_amd import graphed
+    assert isinstance(pot._exact_acc, graphed.ConcurrentAccumulate) and pot._exact_acc.group > 1     # the default route ran
+    gp = torch.cat([p.grad.double().flatten() for p in pot.opt.engine.params])
+    scale = g64.abs().max().item()
+    err_product, err_library = (gp - g64).abs().max().item() / scale, (g32 - g64).abs().max().item() / scale
+    assert abs(loss.item() - l64) <= 1e-6 * abs(l64), (loss.item(), l64)
+    assert err_product <= max(2.0 * err_library, 1e-4), (err_product, err_library)
+    assert err_product <= 5e-3, err_product

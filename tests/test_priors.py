@@ -264,8 +264,11 @@ def test_by_name_priors_run_through_the_sampler_as_leftover(name):
     loss, log_prior, pot_value, acc = pot.minibatch(x, y, True)
     _, lp_ref, potential_ref, _, _ = ref.split_potential_and_acc(x, y, N)
     potential_ref.backward()
-    assert float(log_prior) == pytest.approx(float(lp_ref), rel=2e-5, abs=1e-3)
-    assert float(pot_value) == pytest.approx(float(potential_ref), rel=2e-5, abs=1e-5)
+    parts = dict(fused=float(opt.fused_log_prior()), leftover=float(pot._leftover_log_prior()), ref=float(lp_ref),
+                 ref_parts={n_: float(pr.log_prob()) for n_, pr in P.named_priors(ref) if not getattr(pr, "is_component", False)},
+                 own_parts={n_: float(pr.log_prob()) for n_, pr in P.named_priors(net) if not getattr(pr, "is_component", False)})
+    assert float(log_prior) == pytest.approx(float(lp_ref), rel=2e-5, abs=1e-3), parts
+    assert float(pot_value) == pytest.approx(float(potential_ref), rel=2e-5, abs=1e-5), parts
     for (n_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         want = q.grad if q.grad is not None else torch.zeros_like(q)
         torch.testing.assert_close(p.grad, want, rtol=2e-4, atol=2e-6, msg=lambda m: f"{name} {n_}: {m}")

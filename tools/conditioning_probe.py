@@ -2,7 +2,7 @@
 VerletSGLDReject run (initialisation, after K leapfrog steps) the product's default exact pass (3 lanes x G minibatches
 per launch, persistent convolutions) is compared with a FLOAT64 autograd evaluation of the same quantity at the same
 parameters (the same modules cast to double: every kernel of this package declines float64, so that pass runs on the
-library's double kernels) and with the float32 library path (SGMCMC kernels off) as the yard-stick of what float32
+library's double kernels) and with float32 on the library's kernels (evaluation._plain_torch_layers) as the yard-stick of what float32
 itself costs at that point:  max |g - g64| / max |g64| per parameter tensor, worst tensor reported.
     python tools/conditioning_probe.py [--steps 0,50,200,400]"""
 import argparse
@@ -68,7 +68,9 @@ def main():
         torch.cuda.synchronize()
         buffers = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
         g64, l64 = f64_gradient(model, batches, pot.N)
-        g32, l32 = f64_gradient(model, batches, pot.N, torch.float32)      # float32 on the library path (copy is not the product's modules' kernels? it is: see below)
+        from bnn_priors_amd import evaluation
+        with evaluation._plain_torch_layers():                  # float32 on the LIBRARY's kernels, one minibatch at a time
+            g32, l32 = f64_gradient(model, batches, pot.N, torch.float32)
         loss, _, _ = pot.exact(source)
         torch.cuda.synchronize()
         gp = [p.grad.double().clone() for p in pot.opt.engine.params]
@@ -86,7 +88,7 @@ def main():
         wp, ip, tp = worst(gp)
         w3, i3, t3 = worst(g32)
         print(f"after {done:4d} steps: loss f64 {l64:.6f} product {loss.item():.6f} | product exact pass vs f64: worst tensor "
-              f"{wp:.2e} (#{ip}), whole gradient {tp:.2e} | float32 one-stream autograd of the same modules vs f64: "
+              f"{wp:.2e} (#{ip}), whole gradient {tp:.2e} | float32 library kernels vs f64: "
               f"worst {w3:.2e} (#{i3}), whole {t3:.2e}", flush=True)
 
 
