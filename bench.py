@@ -40,6 +40,11 @@ import statistics
 import sys
 import time
 
+# several chains per GPU run on their own HIP streams: give the process more than the default 4 hardware queues to map
+# them on (read by the HIP runtime when it starts, hence before torch; multichain.concurrent_streams picks streams that
+# really have a queue of their own).  One chain's rate does not depend on it (profiles/r05_chains_per_gpu.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -478,9 +483,11 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
     name, xshape, N, prior = WORKLOADS[args.workload]
     pool = PoolSource(args.workload, N, device, 4321 + rank)           # read-only: shared by the chains
     batches = [b for b in pool if len(b[0]) == 128]
+    from bnn_priors_amd import multichain
     runners, streams, steps_of = [], [], []
+    picked = multichain.concurrent_streams(max(ks), device)        # streams that do not share a hardware queue
     for c in range(max(ks)):
-        st = torch.cuda.Stream(device=device)
+        st = picked[c % len(picked)]
         with torch.cuda.stream(st):
             model = make_model(args.workload, device, args.weight_prior)
             loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
@@ -512,6 +519,7 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
         torch.cuda.synchronize(device)
         ts = time.perf_counter()
         run(steps)
+        t_issued = time.perf_counter() - ts        # the host is done issuing: below the wall time = the GPU is the bound
         for c in range(K):
             with torch.cuda.stream(streams[c]):
                 runners[c]._drain_rows()
@@ -520,7 +528,9 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
         for c in range(K):
             runners[c]._check_finite()
         out[str(K)] = {"aggregate_steps_per_s": round(K * steps / dt, 1), "per_chain_steps_per_s": round(steps / dt, 1),
-                       "us_per_lockstep": round(dt / steps * 1e6, 2)}
+                       "us_per_lockstep": round(dt / steps * 1e6, 2),
+                       "host_issue_us_per_lockstep": round(t_issued / steps * 1e6, 2)}
+    out["distinct_hw_queues"] = len(picked)
     return out
 
 

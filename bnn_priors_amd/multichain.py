@@ -10,7 +10,48 @@ Philox stream = ``chain_id`` -- scheduled differently.  For the dense classifier
     runners = [runner_class("VerletSGLDReject")(model=make_model(), ..., seed=1234, chain_id=c) for c in range(2)]
     multichain.run_on_streams(runners)         # == r.run() for every r, interleaved step by step
 """
+import time
+
 import torch
+
+
+def _spin_time(streams, device, cycles, links):
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for s in streams:
+        with torch.cuda.stream(s):
+            for _ in range(links):
+                torch.cuda._sleep(cycles)
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - t0
+
+
+def concurrent_streams(k, device, candidates=None, cycles=400_000, links=3):
+    """``k`` HIP streams that the GPU really runs side by side.
+
+    HIP multiplexes a process's streams onto a few hardware queues (``GPU_MAX_HW_QUEUES``, 4 unless the variable is set
+    before the runtime starts) and two streams that share a queue run their work back to back: measured in round 5,
+    chains 3 and 4 of ``run_on_streams`` landed on the queues of chains 1 and 2 and the aggregate fell back to two
+    chains' throughput (profiles/r05_chains_per_gpu.txt).  Which stream shares which queue is not an API property, so
+    it is measured: every candidate is raced against the streams already chosen with chains of one-thread spin
+    kernels (a queue slot and nothing else) and kept when the race takes one chain's time rather than two.  A few
+    milliseconds, once.  Returns fewer than ``k`` streams only if the process does not have that many queues."""
+    device = torch.device(device)
+    chosen = []
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates or max(4 * k, 16))]
+    for s in pool:                                   # first use of a stream creates its queue: not inside the race
+        _spin_time([s], device, 1000, 1)
+    alone = min(_spin_time([pool[0]], device, cycles, links) for _ in range(3))
+    for s in pool:
+        if len(chosen) == k:
+            break
+        if not chosen:
+            chosen.append(s)
+            continue
+        raced = min(_spin_time(chosen + [s], device, cycles, links) for _ in range(2))
+        if raced < 1.5 * alone:                      # (a shared queue gives >= 2.0, distinct queues ~1.0)
+            chosen.append(s)
+    return chosen
 
 
 def run_on_streams(runners, streams=None):
@@ -21,7 +62,9 @@ def run_on_streams(runners, streams=None):
         return
     device = next(runners[0].model.parameters()).device
     if streams is None:
-        streams = [torch.cuda.Stream(device=device) for _ in runners]
+        streams = concurrent_streams(len(runners), device)
+        while len(streams) < len(runners):             # fewer hardware queues than chains: the rest share
+            streams.append(streams[len(streams) % max(1, len(streams))])
     main = torch.cuda.current_stream(device)
     for s in streams:
         s.wait_stream(main)

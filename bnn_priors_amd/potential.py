@@ -69,6 +69,11 @@ class Potential:
             return loss, log_prior, potential, accs.mean()
         with _conv.deferring(self.model):      # this pass's convolution weight-gradient slabs: one reduction at its end
             extra = self._leftover_log_prior()
+            if extra is not None:
+                # a tensor with a leftover prior receives TWO gradients in this backward (the likelihood's and the prior's
+                # log-density's); autograd adds them as soon as both exist, so the likelihood's must be complete then:
+                # count the prior as a use of its tensors -- their weight-gradient slabs are reduced at once (conv._may_defer)
+                _conv._note_use(*{id(p): p for pr in self.leftover for p in pr.parameters()}.values())
             if extra is None:
                 with _pool.head_loss(y, head=_pool.head_of(self.model)):                        # a fused head also takes the loss and both backward passes
                     f = self._logits(x)

@@ -327,7 +327,8 @@ def test_hmc_trajectories_and_temperature_on_gpu(T):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["VerletSGLDReject_googleresnet", "VerletSGLDReject_convnet_laplace", "HMCReject"])
 def test_chains_interleaved_on_streams_equal_chains_run_alone(name):
-    """multichain.run_on_streams: two chains (chain_id 0, 1), each on its own HIP stream of the one GPU, advanced step by
+    """multichain.run_on_streams: FOUR chains (chain_id 0 .. 3), each on its own HIP stream of the one GPU (streams chosen
+    so that no two share a hardware queue: multichain.concurrent_streams), advanced step by
     step from one process -- every chain's metric streams and samples are bit-identical to the same chain's ``run()``.
     (As in the reference, the INITIAL full-data pass iterates the shuffling loader before the per-cycle seed exists, i.e.
     it draws its order from torch's global generator -- and BatchNorm makes the potential depend on the batches'
@@ -349,12 +350,15 @@ def test_chains_interleaved_on_streams_equal_chains_run_alone(name):
         runner.begin = lambda: (torch.manual_seed(RC.SEED + chain), begin())[1]
         return runner, metrics
 
+    chains = (0, 1, 2, 3)
     alone = []
-    for chain in (0, 1):
+    for chain in chains:
         runner, metrics = make(chain)
         runner.run()
         alone.append((RC.streams_of(metrics), {k: v.clone() for k, v in runner.get_samples().items()}))
-    pairs = [make(chain) for chain in (0, 1)]
+    pairs = [make(chain) for chain in chains]
+    streams = multichain.concurrent_streams(len(chains), dev)
+    assert len(streams) >= 3, "this process has fewer than three hardware queues for its streams"
     multichain.run_on_streams([r for r, _ in pairs])
     for chain, (runner, metrics) in enumerate(pairs):
         s1, p1 = RC.streams_of(metrics), runner.get_samples()
