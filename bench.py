@@ -115,7 +115,7 @@ def parse():
                          "calibration); stdout carries only the compact line (< 4 KB)")
     ap.add_argument("--stream-chains", default=None,
                     help="googleresnet / convnet: aggregate steps/s of K chains on K HIP streams of ONE GPU, e.g. '1,2,3' "
-                         "(after the timed region; default: '1,2' for a one-GPU googleresnet run, '' = skip)")
+                         "(after the timed region; default: '1,2,4' for a one-GPU googleresnet run, '' = skip)")
     return ap.parse_args()
 
 
@@ -1142,7 +1142,7 @@ def main():
             out["chains_per_gpu"] = chains_per_gpu_sweep(args, device, rank, [int(k) for k in args.chain_sweep.split(",")])
         stream_chains = args.stream_chains
         if stream_chains is None:
-            stream_chains = "1,2" if (args.workload == "googleresnet" and world == 1 and not args.eager) else ""
+            stream_chains = "1,2,4" if (args.workload == "googleresnet" and world == 1 and not args.eager) else ""
         if args.workload != "densenet" and stream_chains and args.inference == "VerletSGLDReject":
             try:
                 out["chains_per_gpu"] = dict(
