@@ -26,32 +26,45 @@ def _spin_time(streams, device, cycles, links):
     return time.perf_counter() - t0
 
 
-def concurrent_streams(k, device, candidates=None, cycles=400_000, links=3):
-    """``k`` HIP streams that the GPU really runs side by side.
+_distinct = {}      # device index -> streams measured to own a hardware queue each (once per process and device)
+
+
+def concurrent_streams(k, device, exclude=(), candidates=16, cycles=400_000, links=3):
+    """Up to ``k`` HIP streams that the GPU really runs side by side (none of them in ``exclude``).
 
     HIP multiplexes a process's streams onto a few hardware queues (``GPU_MAX_HW_QUEUES``, 4 unless the variable is set
     before the runtime starts) and two streams that share a queue run their work back to back: measured in round 5,
     chains 3 and 4 of ``run_on_streams`` landed on the queues of chains 1 and 2 and the aggregate fell back to two
     chains' throughput (profiles/r05_chains_per_gpu.txt).  Which stream shares which queue is not an API property, so
-    it is measured: every candidate is raced against the streams already chosen with chains of one-thread spin
-    kernels (a queue slot and nothing else) and kept when the race takes one chain's time rather than two.  A few
-    milliseconds, once.  Returns fewer than ``k`` streams only if the process does not have that many queues."""
+    it is measured, once per device: every candidate is raced against the streams already chosen with chains of
+    one-thread spin kernels (a queue slot and nothing else) and kept when the race takes one chain's time rather than
+    two -- about 20 ms.  Returns fewer than ``k`` streams if the process does not have that many queues."""
     device = torch.device(device)
-    chosen = []
-    pool = [torch.cuda.Stream(device=device) for _ in range(candidates or max(4 * k, 16))]
-    for s in pool:                                   # first use of a stream creates its queue: not inside the race
-        _spin_time([s], device, 1000, 1)
-    alone = min(_spin_time([pool[0]], device, cycles, links) for _ in range(3))
-    for s in pool:
-        if len(chosen) == k:
-            break
-        if not chosen:
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    chosen = _distinct.get(device.index)
+    if chosen is None:
+        chosen = []
+        pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+        for s in pool:                                   # first use of a stream creates its queue: not inside the race
+            _spin_time([s], device, 1000, 1)
+        alone = min(_spin_time([pool[0]], device, cycles, links) for _ in range(3))
+        for s in pool:
+            if len(chosen) == 8:
+                break
+            if chosen:
+                raced = min(_spin_time(chosen + [s], device, cycles, links) for _ in range(2))
+                if raced >= 1.5 * alone:                 # (a shared queue gives >= 2.0, distinct queues ~1.0)
+                    continue
             chosen.append(s)
-            continue
-        raced = min(_spin_time(chosen + [s], device, cycles, links) for _ in range(2))
-        if raced < 1.5 * alone:                      # (a shared queue gives >= 2.0, distinct queues ~1.0)
-            chosen.append(s)
-    return chosen
+        _distinct[device.index] = chosen
+    skip = {e.cuda_stream for e in exclude}
+    return [s for s in chosen if s.cuda_stream not in skip][:k]
+
+
+def spread(streams, n):
+    "``n`` streams out of ``streams``, cycling when there are fewer (work on a shared stream simply runs back to back)"
+    return [streams[i % len(streams)] for i in range(n)]
 
 
 def run_on_streams(runners, streams=None):
@@ -62,9 +75,7 @@ def run_on_streams(runners, streams=None):
         return
     device = next(runners[0].model.parameters()).device
     if streams is None:
-        streams = concurrent_streams(len(runners), device)
-        while len(streams) < len(runners):             # fewer hardware queues than chains: the rest share
-            streams.append(streams[len(streams) % max(1, len(streams))])
+        streams = spread(concurrent_streams(len(runners), device), len(runners))
     main = torch.cuda.current_stream(device)
     for s in streams:
         s.wait_stream(main)
