@@ -51,7 +51,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the BASELINE configurations contain no library compute kernel in a gradient evaluation: make a silent fallback
 # (a shape off the kernel tables dispatching to MIOpen / rocBLAS) an error instead of a slower number
-os.environ.setdefault("SGMCMC_STRICT", "1")
+if __name__ == "__main__":        # (not when a test imports this file: the variable would leak into that process and its children)
+    os.environ.setdefault("SGMCMC_STRICT", "1")
 
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), same guide

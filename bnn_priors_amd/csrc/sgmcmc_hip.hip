@@ -44,6 +44,34 @@ static hipEvent_t e0 = nullptr, e1 = nullptr;
     }                                                                                                  \
   } while (0)
 
+// Activation-sized outputs are stored WRITE-THROUGH (global_store ... sc0 sc1): the lines leave the XCD's L2 while the
+// kernel still runs, instead of in the write-back at its end that the next launch of the chain waits for -- measured in
+// the googleresnet step (round 5, tools/ab_table.sh): forward convolutions -0.9 us per launch.  Their consumer is the NEXT
+// launch, on whatever XCD: it never could count on finding the line in its own L2.  SGMCMC_WT_STORES is a mask of kernel
+// families (A/B builds): 1 trunk convolutions, 2 BatchNorm, 4 down-sampling / stem convolutions (forward), 8 head / pooling,
+// 16 the 50-channel classifier's layers, 32 persistent convolutions, 64 the trunk's data gradients (measured +0.3 us per
+// merged backward launch: off; the down-sampling block's data gradient +1 us: always plain).
+#ifndef SGMCMC_WT_STORES
+#define SGMCMC_WT_STORES 15
+#endif
+using sgmcmc_f32x4 = __attribute__((ext_vector_type(4))) float;
+// `base`: the tensor's base pointer as the kernel received it (uniform: the buffer descriptor lives in scalar registers);
+// `p`: this lane's 16-byte aligned element pointer inside that tensor.  The store goes through the compiler's own buffer
+// -store builtin (cache policy sc0 sc1), NOT through inline assembly: an asm store is invisible to the hazard recogniser
+// -- round 5's first A/B build stored accumulators that the matrix pipe had not written back yet (tools/lab/conv_bits.py).
+template <int FAMILY>
+__device__ __forceinline__ void sgmcmc_store4(float* __restrict__ base, float* __restrict__ p, float a, float b, float c, float d) {
+  if constexpr ((SGMCMC_WT_STORES & FAMILY) != 0) {
+    const uint64_t off = (uint64_t)(reinterpret_cast<char*>(p) - reinterpret_cast<char*>(base));
+    if (off < 0xfffffff0ull) {           // (a descriptor addresses 4 GiB; beyond it: a plain store)
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(sgmcmc_f32x4{a, b, c, d}, r, (int)(uint32_t)off, 0, /*sc0 | sc1*/ 17);
+      return;
+    }
+  }
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
 // Every entry point reports ITS launches through hipGetLastError().  That state is process-wide and
 // sticky: a failed pointer query inside another library (ATen's pinned-memory checks leave
 // hipErrorInvalidValue behind) would otherwise surface here as if one of our launches had failed.
