@@ -475,7 +475,7 @@ def flat_arena_point(log2n, device, iters=20):
 
 
 # ------------------------------------------------------------------ several chains per GPU (captured-graph nets)
-def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
+def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30, cycles=0):
     """K independent chains of a captured-graph workload (googleresnet, convnet) on ONE GPU, each on its own HIP
     stream: the chains' dependent launch chains interleave on the GPU (a step is ~90 dependent kernels, each of which
     leaves the GPU partly idle at its boundaries).  Aggregate leapfrog steps/s = K * steps / time, per K."""
@@ -531,6 +531,31 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30):
         out[str(K)] = {"aggregate_steps_per_s": round(K * steps / dt, 1), "per_chain_steps_per_s": round(steps / dt, 1),
                        "us_per_lockstep": round(dt / steps * 1e6, 2),
                        "host_issue_us_per_lockstep": round(t_issued / steps * 1e6, 2)}
+        if cycles > 0:
+            # stored samples/s of the K chains together: every chain walks ITS epoch (the runner's own batch stream,
+            # ragged last minibatch included) in lock-step with the others, then each takes its Metropolis-Hastings point
+            # (exact full-data pass on the measured lanes, final_step, test, initial_step) -- what
+            # multichain.run_on_streams does per sample cycle (inference_reject.py:86-157 per chain)
+            def cycle():
+                gens = [runners[c]._hot_batches() for c in range(K)]
+                n_b = len(runners[0]._batches())
+                accs = [0.0] * K
+                for i, row in enumerate(zip(*gens)):
+                    for c, (x, y) in enumerate(row):
+                        steps_of[c] += 1
+                        with torch.cuda.stream(streams[c]):
+                            accs[c] = runners[c].leapfrog(steps_of[c], x, y, last_of_epoch=(i == n_b - 1))
+                for c in range(K):
+                    with torch.cuda.stream(streams[c]):
+                        runners[c]._drain_rows()
+                        steps_of[c] = runners[c]._mh_point(steps_of[c], accs[c], runners[c]._batches())
+            cycle()
+            torch.cuda.synchronize(device)
+            ts = time.perf_counter()
+            for _ in range(cycles):
+                cycle()
+            torch.cuda.synchronize(device)
+            out[str(K)]["aggregate_samples_per_s"] = round(K * cycles / (time.perf_counter() - ts), 3)
     out["distinct_hw_queues"] = len(picked)
     return out
 
@@ -807,6 +832,9 @@ def compact_line(out, detail_path):
     if isinstance(cg, dict):
         line["chains_per_gpu"] = {k: v["aggregate_steps_per_s"] for k, v in cg.items()
                                   if isinstance(v, dict) and "aggregate_steps_per_s" in v}
+        sm = {k: v["aggregate_samples_per_s"] for k, v in cg.items() if isinstance(v, dict) and "aggregate_samples_per_s" in v}
+        if sm:
+            line["chains_per_gpu_samples_per_s"] = sm
     if out.get("exchange"):
         line["exchange"] = pick(out["exchange"], ("chains", "ensemble_ms", "gather_ms", "ensemble_matches_single_process",
                                                   "gather_order_checked"))
@@ -1147,7 +1175,8 @@ def main():
         if args.workload != "densenet" and stream_chains and args.inference == "VerletSGLDReject":
             try:
                 out["chains_per_gpu"] = dict(
-                    chains_per_gpu_streams(args, device, rank, [int(k) for k in stream_chains.split(",")]),
+                    chains_per_gpu_streams(args, device, rank, [int(k) for k in stream_chains.split(",")],
+                                           cycles=2 if args.samples >= 10 else 0),
                     method="K runners, each with its own captured step on its own HIP stream (no augmentation gather)")
             except Exception as exc:       # an extension after the timed region: never takes the bench line down
                 out["chains_per_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
