@@ -60,12 +60,12 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
         _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, st.data_ptr(), s), "fwd")
     nb = n * (hw // 8) * (c // 16)
     f = stamps(nb)
-    report(f"forward {c}@{hw}", f, [("fwd", slice(0, nb), ((1, "half 0 in LDS"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
+    report(f"forward {c}@{hw}", f, [("fwd", slice(0, nb), ((1, "half 0 in LDS"), (4, "B in registers"), (5, "half 0 MFMAs issued"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
     for rep in range(3):
         flush.normal_()
         _hip.check(lib.sgmcmc_conv3x3(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, c, hw, 1, 0, s), "dgrad")
     f = stamps(nb)
-    report(f"data gradient alone {c}@{hw} (transposed weights, no epilogue)", f, [("dgrad", slice(0, nb), ((1, "half 0 in LDS"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
+    report(f"data gradient alone {c}@{hw} (transposed weights, no epilogue)", f, [("dgrad", slice(0, nb), ((1, "half 0 in LDS"), (4, "B in registers"), (5, "half 0 MFMAs issued"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
     for rep in range(3):
         flush.normal_()
         _hip.check(lib.sgmcmc_conv3x3_wrw(x.data_ptr(), dy.data_ptr(), w.data_ptr() * 0 + torch.empty_like(w).data_ptr(), scratch.data_ptr(), n, c, hw, s), "wrw")
