@@ -94,3 +94,23 @@ def test_gather_samples_gloo_world2(tmp_path):
     assert got["a.p"].shape == (5, 3, 2)
     assert got["a.p"][:2].eq(0).all() and got["a.p"][2:].eq(1).all()
     assert got["steps"].tolist() == [0, 1, 10, 11, 12]
+
+
+# ---- several chains on ONE GPU: streams that own a hardware queue (bnn_priors_amd/multichain.py) ----------------------
+@pytest.mark.gpu
+def test_concurrent_streams_really_run_side_by_side():
+    """multichain.concurrent_streams: the streams it hands out are distinct, none of them is an excluded one, the set is
+    measured once per device -- and K chains of spin kernels on them take one chain's time, not K (two streams on one
+    hardware queue, what round 4's chains 3 and 4 had, take twice as long)."""
+    from bnn_priors_amd import multichain
+    dev = torch.device("cuda", 0)
+    picked = multichain.concurrent_streams(3, dev)
+    assert 2 <= len(picked) <= 3 and len({s.cuda_stream for s in picked}) == len(picked)
+    again = multichain.concurrent_streams(3, dev)
+    assert [s.cuda_stream for s in again] == [s.cuda_stream for s in picked]              # memoised
+    rest = multichain.concurrent_streams(3, dev, exclude=[picked[0]])
+    assert picked[0].cuda_stream not in {s.cuda_stream for s in rest}
+    alone = min(multichain._spin_time(picked[:1], dev, 400_000, 3) for _ in range(3))
+    together = min(multichain._spin_time(picked, dev, 400_000, 3) for _ in range(3))
+    assert together < 1.5 * alone, (alone, together)
+    assert len(multichain.spread(picked, 5)) == 5
