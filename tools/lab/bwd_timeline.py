@@ -46,7 +46,7 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     w = torch.randn((c, c, 3, 3), generator=g, device=dev) * (2.0 / (9 * c)) ** .5
     y, dx, out = torch.zeros_like(x), torch.zeros_like(x), torch.relu(torch.randn((n, c, hw, hw), generator=g, device=dev))
     slices = lib.sgmcmc_conv3x3_stat_slices(n, c, hw)
-    st = torch.zeros((c, slices, 2), dtype=torch.float64, device=dev)
+    st = torch.zeros((c, slices * 2, 2), dtype=torch.float64, device=dev)      # (room for a lab build with 4-row bands)
     scratch = torch.zeros(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), device=dev)
     saved = torch.stack([torch.zeros(c, device=dev), torch.ones(c, device=dev)])
     part = torch.zeros((c, slices, 2), dtype=torch.float64, device=dev)
@@ -58,9 +58,10 @@ for c, hw in ((16, 32), (32, 16), (64, 8)):
     for rep in range(3):
         flush.normal_()          # something else in the caches, as in the step
         _hip.check(lib.sgmcmc_conv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, hw, 0, st.data_ptr(), s), "fwd")
-    nb = n * (hw // 8) * (c // 16)
+    nb = n * (hw // int(os.environ.get("FWD_ROWS", "8"))) * (c // 16) if c < 64 else n * (hw // 8) * (c // 16)
     f = stamps(nb)
-    report(f"forward {c}@{hw}", f, [("fwd", slice(0, nb), ((1, "half 0 in LDS"), (4, "B in registers"), (5, "half 0 MFMAs issued"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
+    nb_fwd, nb = nb, n * (hw // 8) * (c // 16)
+    report(f"forward {c}@{hw}", f, [("fwd", slice(0, nb_fwd), ((1, "half 0 in LDS"), (4, "B in registers"), (5, "half 0 MFMAs issued"), (2, "half 1 in LDS"), (3, "MFMAs + stores issued"), (6, "end")))])
     for rep in range(3):
         flush.normal_()
         _hip.check(lib.sgmcmc_conv3x3(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, c, hw, 1, 0, s), "dgrad")
