@@ -43,6 +43,23 @@ def test_compact_line_is_small_and_complete():
     assert line["value"] == out["value"] and line["roofline"]["frac"] == top["frac"]
 
 
+def test_compact_line_carries_chains_per_gpu_as_steps_and_as_samples():
+    out = _full_record()
+    out["chains_per_gpu"] = {str(k): {"aggregate_steps_per_s": 1000.0 * k ** .5, "per_chain_steps_per_s": 1.0, "us_per_lockstep": 1.0,
+                                      "host_issue_us_per_lockstep": 1.0, "block_us_per_lockstep": [1.0, 1.0, 1.0],
+                                      "aggregate_samples_per_s": 2.0 + k / 10} for k in (1, 2, 4)}
+    out["chains_per_gpu"].update(distinct_hw_queues=6, method="x" * 100)
+    line = json.loads(bench.compact_line(out, None))
+    assert line["chains_per_gpu"] == {"1": 1000.0, "2": 1000.0 * 2 ** .5, "4": 2000.0}
+    assert line["chains_per_gpu_samples_per_s"] == {"1": 2.1, "2": 2.2, "4": 2.4}
+    assert len(json.dumps(line)) < 4096
+
+
+def test_spread_cycles_over_fewer_streams():
+    from bnn_priors_amd import multichain
+    assert multichain.spread(["a", "b", "c"], 5) == ["a", "b", "c", "a", "b"] and multichain.spread(["a"], 2) == ["a", "a"]
+
+
 def test_compact_line_with_eight_ranks_and_every_optional_table():
     out = _full_record()
     out["n_gpus"] = out["ranks_seen"] = 8
