@@ -337,6 +337,9 @@ ALT_EXPORTS = {
                                 + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "sgmcmc_conv3x3_bn_bwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBnBwdArgs)]
                               + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "sgmcmc_conv3x3_bwd_uniform_slabs": (ctypes.c_int, [ctypes.c_int] * 3),
+    "sgmcmc_conv3x3_bwd_uniform": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.POINTER(ConvBwdEpilogue), ctypes.c_void_p]
+                                   + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
 }
 if ALTERNATIVES:
     EXPORTS.update(ALT_EXPORTS)

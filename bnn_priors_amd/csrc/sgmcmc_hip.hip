@@ -1498,7 +1498,7 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "bn_hip.inc"
 // Measured alternatives that LOST to the default kernels (the BatchNorm folded into the next
 // convolution's staging, the BatchNorm backward formed inside the convolution-gradient launch, the weight-gradient half
-// on a side stream).  They are kept,
+// on a side stream, round 6's uniform backward convolution).  They are kept,
 // tested and switchable -- but only in a library built with -DSGMCMC_ALTERNATIVES (include/sgmcmc_hip_alternatives.h;
 // SGMCMC_ALTERNATIVES=1 in the environment of bnn_priors_amd._hip.build()): the shipped library and the header a
 // maintainer reads describe the path that runs.
@@ -1506,6 +1506,7 @@ int sgmcmc_debug_normals(float* out, int64_t start, int64_t n, uint64_t seed, ui
 #include "sgmcmc_hip_alternatives.h"
 #include "conv_fused_hip.inc"
 #include "conv_fold_hip.inc"
+#include "conv_uni_hip.inc"
 #endif
 #include "pool_hip.inc"
 #include "augment_hip.inc"

@@ -10,7 +10,10 @@
  *   - sgmcmc_conv3x3_bwd_part            the weight-gradient half of a convolution backward on a side stream: every
  *                                        fork + join edge of a replayed graph costs ~19 us, 1,137 -> 845 steps/s;
  *   - sgmcmc_conv3x3_bn_bwd              the BatchNorm backward formed inside the convolution-gradient launch: needs a
- *                                        sums launch of its own, 1,059 vs 1,122 steps/s.
+ *                                        sums launch of its own, 1,059 vs 1,122 steps/s;
+ *   - sgmcmc_conv3x3_bwd_uniform         (round 6) data gradient + weight-gradient slab of an (image, band) by ONE kind of
+ *                                        workgroup from one staging: 16.7-16.95 vs 17.2-17.55 us per launch in the step,
+ *                                        twice the slabs at 32 channels (reduction +4.6 us): 1,244 vs 1,242.5 steps/s.
  *
  * Same conventions as sgmcmc_hip.h (device pointers, hipStream_t as void*, hipError_t returned as int). */
 #ifndef SGMCMC_HIP_ALTERNATIVES_H
@@ -75,6 +78,17 @@ int sgmcmc_conv3x3_bn_bwd(const float* x, const float* w, float* dx, float* scra
                           const sgmcmc_conv_bn_bwd_args* A, int n_img, int channels, int hw, int* n_slabs,
                           void* stream);
 
+
+/* The UNIFORM backward convolution (csrc/conv_uni_hip.inc) at (channels, hw) = (16, 32) and (32, 16): both gradients of
+ * sgmcmc_conv3x3_bwd_ex (same epilogues; no groups, no wrw_mult) by 8-wave workgroups that stage the dy band (with halo),
+ * the x band and the transposed weight slab ONCE and run the data gradient's and the weight gradient's MFMAs one after the
+ * other.  dx and the sums partials carry the bits of sgmcmc_conv3x3_bwd_ex; the weight gradient is left as
+ * sgmcmc_conv3x3_bwd_uniform_slabs(...) tap-major slabs of channels^2 * 9 floats in `scratch` (one reduction job for
+ * sgmcmc_wrw_reduce_many, taps = 9): one per workgroup = per two (image, band) items at 16 channels, per item at 32. */
+int sgmcmc_conv3x3_bwd_uniform_slabs(int n_img, int channels, int hw);
+int sgmcmc_conv3x3_bwd_uniform(const float* x, const float* w, const float* dy, float* dx,
+                               const sgmcmc_conv_bwd_epilogue* epi, float* scratch, int n_img, int channels, int hw,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -620,3 +620,58 @@ def test_a_convnet_width_off_the_tables_is_loud_not_silent():
         F.cross_entropy(net.net(x), y).backward()
     assert {k[0] for k in conv.LIBRARY_CALLS} == {"conv2d"} and len(conv.LIBRARY_CALLS) == 2, dict(conv.LIBRARY_CALLS)
     conv.LIBRARY_CALLS.clear()
+
+
+@ALT
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw", [(16, 32), (32, 16)])
+@pytest.mark.parametrize("n", [128, 5, 1])
+@pytest.mark.parametrize("epi", ["none", "add_masked+sums", "add+sums+mask_dx"])
+def test_uniform_backward_matches_the_merged_launch(c, hw, n, epi):
+    """round 6's uniform backward convolution (csrc/conv_uni_hip.inc, a measured alternative): dx and the BatchNorm
+    -backward sums carry the BITS of sgmcmc_conv3x3_bwd_ex, the weight gradient agrees with float64 like the default's"""
+    import ctypes
+    lib = _hip.lib()
+    x, w, dy = (t.cuda() for t in _data(c, hw, n))
+    g = torch.Generator().manual_seed(7 + n)
+    e_dout, out = torch.randn(x.shape, generator=g).cuda(), torch.randn(x.shape, generator=g).relu().cuda()
+    y_bn, mean, invstd = torch.randn(x.shape, generator=g).cuda(), torch.randn(c, generator=g).cuda() * .1, \
+        torch.rand(c, generator=g).cuda() + .5
+    s = torch.cuda.current_stream().cuda_stream
+    slices = n * (hw // 8)
+
+    def run(uniform):
+        dx = torch.full_like(x, float("nan"))
+        partial = torch.full((c, slices, 2), float("nan"), dtype=torch.float64, device="cuda")
+        E = _hip.ConvBwdEpilogue()
+        if epi != "none":
+            E.e_dout = e_dout.data_ptr()
+            E.e_out = out.data_ptr() if epi == "add_masked+sums" else None
+            E.s_y, E.s_out, E.s_mean, E.s_invstd = y_bn.data_ptr(), out.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            E.s_partial = partial.data_ptr()
+            E.mask_dx = int(epi.endswith("mask_dx"))
+        dw = torch.empty_like(w)
+        if uniform:
+            P = lib.sgmcmc_conv3x3_bwd_uniform_slabs(n, c, hw)
+            part = torch.empty(P * w.numel(), device="cuda")
+            _hip.check(lib.sgmcmc_conv3x3_bwd_uniform(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
+                                                      part.data_ptr(), n, c, hw, s), "sgmcmc_conv3x3_bwd_uniform")
+            job = (_hip.ReduceJob * 1)()
+            job[0].part, job[0].out, job[0].n_slabs, job[0].numel, job[0].taps = part.data_ptr(), dw.data_ptr(), P, w.numel(), 9
+            _hip.check(lib.sgmcmc_wrw_reduce_many(ctypes.cast(job, ctypes.c_void_p), 1, s), "sgmcmc_wrw_reduce_many")
+        else:
+            part = torch.empty(lib.sgmcmc_conv3x3_wrw_scratch_floats(n, c, hw), device="cuda")
+            _hip.check(lib.sgmcmc_conv3x3_bwd_ex(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctypes.byref(E),
+                                                 dw.data_ptr(), part.data_ptr(), n, c, hw, None, s), "sgmcmc_conv3x3_bwd_ex")
+        torch.cuda.synchronize()
+        return dx, dw, partial
+
+    dx0, dw0, p0 = run(False)
+    dx1, dw1, p1 = run(True)
+    assert torch.equal(dx0, dx1)
+    if epi != "none":
+        assert torch.equal(p0, p1)
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    scale = ref.abs().max().item()
+    assert (dw1.double() - ref).abs().max().item() <= 2e-6 * scale * max(1.0, (n * hw * hw) ** .5 / 32)
+    assert (dw1 - dw0).abs().max().item() <= 4e-6 * scale * max(1.0, (n * hw * hw) ** .5 / 32)

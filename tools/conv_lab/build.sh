@@ -6,3 +6,4 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-r
 hipcc $F -DNO_STAMPS lab.hip -o lab && hipcc $F lab.hip -o lab_st
 hipcc $F -DNO_STAMPS lab50.hip -o lab50 && hipcc $F lab50.hip -o lab50_st
 hipcc $F atom.hip -o atom
+hipcc $F lab_uni.hip -o lab_uni && hipcc $F -DUNI_STAMPS lab_uni.hip -o lab_uni_st
