@@ -43,7 +43,8 @@ import time
 # several chains per GPU run on their own HIP streams: give the process more than the default 4 hardware queues to map
 # them on (read by the HIP runtime when it starts, hence before torch; multichain.concurrent_streams picks streams that
 # really have a queue of their own).  One chain's rate does not depend on it (profiles/r05_chains_per_gpu.txt).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if __name__ == "__main__":        # (not when a test imports this file: the variable would leak into that process and its children)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 
@@ -74,7 +75,7 @@ def parse():
     ap.add_argument("--workload", default="googleresnet", choices=sorted(WORKLOADS))
     ap.add_argument("--min-seconds", type=float, default=0.5, help="keep timing blocks of K steps until this long")
     ap.add_argument("--max-blocks", type=int, default=400)
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU baseline, timed as three blocks (0 = skip)")
     ap.add_argument("--sweep-log2", type=int, default=28, help="flat-arena roofline point, log2(elements); 0 = skip")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture (for comparison)")
@@ -327,7 +328,7 @@ def _stale(committed):
     """True when a committed measurement (profiles/in_step_us.json, pmc_traffic.json) was taken on other kernel sources
     than this tree's: its ``source_sha`` (hash of csrc/* + include/*, bnn_priors_amd._hip.source_sha) differs or is absent."""
     from bnn_priors_amd import _hip
-    return committed.get("source_sha") != _hip.source_sha()
+    return committed.get("source_sha") != _hip.library_sha()
 
 
 def attach_pmc_traffic(rows):
@@ -487,6 +488,7 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30, cycles=
     from bnn_priors_amd import multichain
     runners, streams, steps_of = [], [], []
     picked = multichain.concurrent_streams(max(ks), device)        # streams that do not share a hardware queue
+    multichain.reserve(picked, device)                             # (the chains' exact passes take their lanes from the rest)
     for c in range(max(ks)):
         st = picked[c % len(picked)]
         with torch.cuda.stream(st):
@@ -757,6 +759,27 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+def step_roofline(rows, ms_per_step):
+    """The WHOLE step against the fp32-MFMA peak: the trunk's contraction flops per step (every MFMA row x its launches per
+    step) / the measured step period, with the launch count and GPU-busy time of the committed in-step profile when it
+    belongs to the loaded library (else null)."""
+    flops = sum(r["algorithmic_flops_per_launch"] * r["launches_per_step"] for r in rows
+                if r.get("bound") == "mfma" and r.get("launches_per_step"))
+    ach = flops / (ms_per_step * 1e-3) / 1e12
+    out = dict(flops_per_step=round(flops), achieved_tflops=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
+               frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), launches_per_step=None, gpu_busy_us=None)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "in_step_us.json")
+    try:
+        with open(path) as f:
+            committed = json.load(f)
+        if not _stale(committed):
+            out["launches_per_step"] = committed.get("launches_per_step")
+            out["gpu_busy_us"] = committed.get("gpu_busy_us_per_step")
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 # ------------------------------------------------------------------ the headline roofline row and the compact line
 def _symbol(row):
     "the device symbol a roofline row belongs to: BatchNorm rows of the three stages are ONE kernel, convolutions one per shape"
@@ -781,16 +804,24 @@ def headline_rooflines(rows):
         n = sum(r["launches_per_step"] for r in rs)
         work = sum(r[work_key] * r["launches_per_step"] for r in rs)
         live_us, step_us = tot("avg_kernel_us"), tot("in_step_us")
-        ach = work / (live_us * 1e-6) / scale
+        ach_iso = work / (live_us * 1e-6) / scale
+        in_step = all("in_step_us" in r for r in rs)
+        # achieved / frac are what the kernel does INSIDE the step (rocprofv3 durations of the captured launches,
+        # profiles/in_step_us.json) whenever that measurement belongs to the loaded library; the isolated-launch figure
+        # (dispatch-packet events, measured live: always a few tenths of a microsecond shorter) stays beside it
+        ach = work / (step_us * 1e-6) / scale if in_step else ach_iso
         row = dict(kernel=sym if len(rs) > 1 else rs[0]["kernel"], bound=rs[0]["bound"], achieved=round(ach, 2),
                    peak=rs[0]["peak"], unit=rs[0]["unit"], frac=round(ach / rs[0]["peak"], 4),
+                   frac_source="in_step" if in_step else "isolated",
+                   achieved_isolated=round(ach_iso, 2), frac_isolated=round(ach_iso / rs[0]["peak"], 4),
                    traffic=(round(sum(r["traffic"] * r["launches_per_step"] for r in rs) / n)
                             if all(r.get("traffic") is not None for r in rs) else None),
                    avg_kernel_us=round(live_us / n, 3), launches_per_step=n, us_per_step=round(step_us, 1),
                    shapes=len(rs))
         row[work_key] = round(work / n)
-        if all("in_step_us" in r for r in rs):
-            row["frac_in_step"] = round(work / (step_us * 1e-6) / scale / rs[0]["peak"], 4)
+        if in_step:
+            row["frac_in_step"] = row["frac"]
+            row["in_step_us"] = round(step_us / n, 3)
         elif any(r.get("stale") for r in rs):
             row["stale"] = True         # profiles/in_step_us.json was measured on other kernel sources
         return row
@@ -802,7 +833,7 @@ def headline_rooflines(rows):
     return top, other
 
 
-_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_in_step", "stale", "traffic",
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_source", "frac_isolated", "stale", "traffic", "in_step_us",
               "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "avg_kernel_us", "avg_kernel_ms",
               "launches_per_step", "us_per_step", "elements")
 
@@ -825,8 +856,11 @@ def compact_line(out, detail_path):
     for k in ("roofline", "roofline_mfma", "roofline_hbm", "roofline_sampler", "roofline_flat_arena"):
         if out.get(k) is not None:
             line[k] = pick(out[k], _ROOF_KEYS)
+    if out.get("roofline_step") is not None:
+        line["roofline_step"] = out["roofline_step"]
     if out.get("cpu_baseline"):
-        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "host_cpus", "kind"))
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "host_cpus", "kind", "cpu_model",
+                                                          "block_steps_per_s", "threads_calibration_steps_per_s"))
         line["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:160]
         line["speedup_vs_cpu"] = out.get("speedup_vs_cpu")
     if out.get("samples_per_sec"):
@@ -839,6 +873,9 @@ def compact_line(out, detail_path):
         sm = {k: v["aggregate_samples_per_s"] for k, v in cg.items() if isinstance(v, dict) and "aggregate_samples_per_s" in v}
         if sm:
             line["chains_per_gpu_samples_per_s"] = sm
+        # (the K > 1 figures depend on how many hardware queues the process was given: say so next to them)
+        line["chains_per_gpu_queues"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                                         "distinct_hw_queues": cg.get("distinct_hw_queues")}
     if out.get("exchange"):
         line["exchange"] = pick(out["exchange"], ("chains", "ensemble_ms", "gather_ms", "ensemble_matches_single_process",
                                                   "gather_order_checked"))
@@ -869,9 +906,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
-    if world != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE = {world}: the launcher's --nproc-per-node and "
-                         "--gpus must agree")
+    # --gpus counts the ranks of ONE node (the launcher's --nproc-per-node = LOCAL_WORLD_SIZE); a multi-node launch has
+    # WORLD_SIZE = nodes x that
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if local_world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but LOCAL_WORLD_SIZE = {local_world}: the launcher's "
+                         "--nproc-per-node and --gpus must agree")
     n_dev = torch.cuda.device_count()
     if local >= n_dev and args.backend != "gloo":
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {n_dev} GPU(s) visible (ranks may share a GPU only with "
@@ -1165,6 +1205,7 @@ def main():
                                     "(else stale: true and no in-step figure); traffic from profiles/pmc_traffic.json "
                                     "under the same rule")
             out["roofline_kernels"] = rows_all_k
+            out["roofline_step"] = step_roofline(rows_all_k, out["ms_per_step"])
             if sampler_line:
                 out["roofline_sampler"] = sampler_line
         elif sampler_line:
@@ -1175,7 +1216,7 @@ def main():
             out["chains_per_gpu"] = chains_per_gpu_sweep(args, device, rank, [int(k) for k in args.chain_sweep.split(",")])
         stream_chains = args.stream_chains
         if stream_chains is None:
-            stream_chains = "1,2,4" if (args.workload == "googleresnet" and world == 1 and not args.eager) else ""
+            stream_chains = "1,2,4,8" if (args.workload == "googleresnet" and world == 1 and not args.eager) else ""
         if args.workload != "densenet" and stream_chains and args.inference == "VerletSGLDReject":
             try:
                 out["chains_per_gpu"] = dict(
@@ -1205,14 +1246,14 @@ def main():
                                     steps_per_cycle=L * 50, budget_s=args.cpu_budget)
             out["cpu_baseline"] = {
                 "value": round(res["steps_per_s"], 2), "unit": "steps/s", "cores": res["cores"],
-                "kind": "port", "host_cpus": res["host_cpus"],
-                "threads_calibration_steps_per_s": res["calibration"],
-                "sample": f"{res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
+                "kind": "port", "host_cpus": res["host_cpus"], "cpu_model": res["cpu_model"],
+                "threads_calibration_steps_per_s": res["calibration"], "block_steps_per_s": res["block_steps_per_s"],
+                "sample": f"median of {len(res['block_steps_per_s'])} blocks: {res['steps']} leapfrog steps in {res['seconds']:.1f} s of the same workload "
                           "(oracle/: reference-op-order torch-CPU loop on oracle/nets.py's plain-torch restatement of "
                           "the net, per-tensor sampler)"}
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
         from bnn_priors_amd import _hip
-        out["source_sha"] = _hip.source_sha()
+        out["source_sha"] = _hip.library_sha()
         detail_path = args.detail or None
         if detail_path:
             try:

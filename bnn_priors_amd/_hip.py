@@ -170,6 +170,7 @@ MAX_CHAINS, MLP_BATCH_MULTI = 8, 128
 
 EXPORTS = {
     "sgmcmc_abi_version": (ctypes.c_int, []),
+    "sgmcmc_source_sha": (ctypes.c_char_p, []),
     "sgmcmc_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "sgmcmc_step": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs), ctypes.c_void_p]),
     "sgmcmc_step_timed": (ctypes.c_int, [ctypes.POINTER(Layout), ctypes.POINTER(StepArgs),
@@ -368,8 +369,24 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.sgmcmc_abi_version() != ABI_VERSION:
             raise HipExtensionMissing(f"ABI mismatch: library {L.sgmcmc_abi_version()} != {ABI_VERSION}")
+        # the binary must be the one these sources compile to: a library left over from before an edit of csrc/ would
+        # otherwise run -- and be measured -- under the tree's name.  A variant build (tools/build_variant.sh) carries
+        # "<sha>+<flags>"; SGMCMC_ALLOW_STALE_LIB=1 turns the refusal into a warning (bisecting with an old binary).
+        built_from, tree = L.sgmcmc_source_sha().decode(), source_sha()
+        if built_from.split("+")[0] != tree:
+            msg = (f"{LIB_PATH} was built from sources {built_from!r}, the tree is {tree!r}: rebuild it "
+                   f"(python -c 'import __graft_entry__ as g; g.build()')")
+            if os.environ.get("SGMCMC_ALLOW_STALE_LIB", "0") != "1":
+                raise HipExtensionMissing(msg)
+            import warnings
+            warnings.warn(msg)
         _lib = L
     return _lib
+
+
+def library_sha():
+    "what the LOADED library says it was built from: the stamp of every measurement (bench.py, tools/step_summary.py)"
+    return lib().sgmcmc_source_sha().decode()
 
 
 def check(err, what):
@@ -396,7 +413,8 @@ def build(verbose=False):
     """hipcc cross-compile for gfx950 (works without a GPU)."""
     import subprocess
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc", *HIPCC_FLAGS, *(["-DSGMCMC_ALTERNATIVES"] if ALTERNATIVES else []), "-I", INCLUDE_DIR,
+    cmd = ["hipcc", *HIPCC_FLAGS, *(["-DSGMCMC_ALTERNATIVES"] if ALTERNATIVES else []),
+           f'-DSGMCMC_SOURCE_SHA="{source_sha()}"', "-I", INCLUDE_DIR,
            "-I", os.path.join(_HERE, "csrc"), *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -1269,6 +1269,13 @@ void launch_finalize(const sgmcmc_layout* L, const sgmcmc_step_args* A, const sg
 extern "C" {
 
 int sgmcmc_abi_version(void) { return SGMCMC_ABI_VERSION; }
+// The hash of the sources this binary was compiled from (bnn_priors_amd._hip.source_sha(), handed in by the build as
+// -DSGMCMC_SOURCE_SHA="..."; a variant build appends its extra flags): the loader refuses a library whose hash is not the
+// tree's, and measurements are stamped with THIS string, not with a hash of whatever files lie next to the binary.
+#ifndef SGMCMC_SOURCE_SHA
+#define SGMCMC_SOURCE_SHA "unstamped"
+#endif
+const char* sgmcmc_source_sha(void) { return SGMCMC_SOURCE_SHA; }
 
 const char* sgmcmc_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 

@@ -490,8 +490,8 @@ class ConcurrentAccumulate:
         self.group = G = pick_group(n_full, x_example.shape[0], lanes, group)
         # lanes that share a hardware queue run back to back (round 5: the third lane was slower than two for that reason)
         from . import multichain
-        own = multichain.concurrent_streams(lanes, dev, exclude=[torch.cuda.current_stream(dev)])
-        self.streams = multichain.spread(own, lanes) if own else [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        # (distinct streams, none of them a chain's main stream: multichain.lanes)
+        self.streams = multichain.lanes(lanes, dev, exclude=[torch.cuda.current_stream(dev)])
         self.lanes, self.singles, self.log_cur, self.log_cur1, self.slots1 = [], [], [], [], []
         self.off_shape = {}          # (lane, shapes) -> a captured body for a minibatch of another size (the ragged last one)
         main = torch.cuda.current_stream(dev)

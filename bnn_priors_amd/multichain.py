@@ -26,40 +26,94 @@ def _spin_time(streams, device, cycles, links):
     return time.perf_counter() - t0
 
 
-_distinct = {}      # device index -> streams measured to own a hardware queue each (once per process and device)
+_distinct = {}      # device index -> streams measured to own a hardware queue each
+_probes = {}        # device index -> how often the measurement ran (a busy GPU makes it reject good streams: it is repeated)
+_reserved = {}      # device index -> handles of the streams that carry a chain's own launches (never handed out as lanes)
+MAX_PROBES = 3
+
+
+def _measure(device, candidates, cycles, links):
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+    for s in pool:                                   # first use of a stream creates its queue: not inside the race
+        _spin_time([s], device, 1000, 1)
+    alone = min(_spin_time([pool[0]], device, cycles, links) for _ in range(3))
+    chosen = []
+    for s in pool:
+        if len(chosen) == 8:
+            break
+        if chosen:
+            raced = min(_spin_time(chosen + [s], device, cycles, links) for _ in range(2))
+            if raced >= 1.5 * alone:                 # (a shared queue gives >= 2.0, distinct queues ~1.0)
+                continue
+        chosen.append(s)
+    return chosen
 
 
 def concurrent_streams(k, device, exclude=(), candidates=16, cycles=400_000, links=3):
     """Up to ``k`` HIP streams that the GPU really runs side by side (none of them in ``exclude``).
 
     HIP multiplexes a process's streams onto a few hardware queues (``GPU_MAX_HW_QUEUES``, 4 unless the variable is set
-    before the runtime starts) and two streams that share a queue run their work back to back: measured in round 5,
-    chains 3 and 4 of ``run_on_streams`` landed on the queues of chains 1 and 2 and the aggregate fell back to two
-    chains' throughput (profiles/r05_chains_per_gpu.txt).  Which stream shares which queue is not an API property, so
-    it is measured, once per device: every candidate is raced against the streams already chosen with chains of
+    before the runtime starts -- bench.py sets 8) and two streams that share a queue run their work back
+    to back: measured in round 5, chains 3 and 4 of ``run_on_streams`` landed on the queues of chains 1 and 2 and the
+    aggregate fell back to two chains' throughput (profiles/r05_chains_per_gpu.txt).  Which stream shares which queue is
+    not an API property, so it is measured: every candidate is raced against the streams already chosen with chains of
     one-thread spin kernels (a queue slot and nothing else) and kept when the race takes one chain's time rather than
-    two -- about 20 ms.  Returns fewer than ``k`` streams if the process does not have that many queues."""
+    two -- about 20 ms.  The race is a wall-clock measurement: with other work on the GPU (ranks sharing it over gloo,
+    another process, launches in flight) it rejects streams that are fine.  Hence: a result with fewer than ``k``
+    streams is measured again (up to MAX_PROBES times per device, the largest set kept), one with a single stream is
+    never kept for the process, and falling short is said out loud.  ``SGMCMC_STREAM_PROBE=0`` skips the measurement:
+    ``k`` fresh streams are returned as they are (what round 4 did)."""
+    import os
+    import warnings
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    chosen = _distinct.get(device.index)
-    if chosen is None:
-        chosen = []
-        pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
-        for s in pool:                                   # first use of a stream creates its queue: not inside the race
-            _spin_time([s], device, 1000, 1)
-        alone = min(_spin_time([pool[0]], device, cycles, links) for _ in range(3))
-        for s in pool:
-            if len(chosen) == 8:
-                break
-            if chosen:
-                raced = min(_spin_time(chosen + [s], device, cycles, links) for _ in range(2))
-                if raced >= 1.5 * alone:                 # (a shared queue gives >= 2.0, distinct queues ~1.0)
-                    continue
-            chosen.append(s)
-        _distinct[device.index] = chosen
     skip = {e.cuda_stream for e in exclude}
-    return [s for s in chosen if s.cuda_stream not in skip][:k]
+    if os.environ.get("SGMCMC_STREAM_PROBE", "1") == "0":
+        return [torch.cuda.Stream(device=device) for _ in range(k)]
+
+    def usable(chosen):
+        return [s for s in chosen if s.cuda_stream not in skip]
+    chosen = _distinct.get(device.index, [])
+    while len(usable(chosen)) < k and len(chosen) < 8 and _probes.get(device.index, 0) < MAX_PROBES:
+        _probes[device.index] = _probes.get(device.index, 0) + 1
+        again = _measure(device, candidates, cycles, links)
+        if len(again) > len(chosen):
+            chosen = again
+        if len(chosen) > 1:
+            _distinct[device.index] = chosen
+    out = usable(chosen)[:k]
+    if len(out) < k:
+        warnings.warn(f"multichain: {len(out)} concurrent HIP stream(s) found where {k} were asked for (GPU_MAX_HW_QUEUES="
+                      f"{os.environ.get('GPU_MAX_HW_QUEUES', 'unset: 4')}; a GPU that is busy during the 20 ms probe also "
+                      "hides queues): chains / lanes beyond that share streams and run back to back", stacklevel=2)
+    return out
+
+
+def reserve(streams, device):
+    "these streams carry a chain's own launches from now on: ``lanes`` never hands them out"
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    _reserved.setdefault(idx, set()).update(s.cuda_stream for s in streams)
+
+
+def lanes(k, device, exclude=()):
+    """``k`` DISTINCT streams for helper lanes (the exact pass's ``ConcurrentAccumulate``): measured-concurrent streams
+    that are nobody's main stream (``reserve``) and not in ``exclude``; when the measured set has fewer, FRESH streams make
+    up the number -- a fresh stream may share a hardware queue with another one, but no lane is the same stream twice and
+    no lane queues behind another chain's steps (round 5 took the lanes from the chains' own pool: with K chains a
+    chain's exact pass ran on the other chains' main streams and the K > 1 samples/s figures contained that
+    serialisation)."""
+    import warnings
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    taken = _reserved.get(idx, set()) | {e.cuda_stream for e in exclude}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pool = [s for s in concurrent_streams(8, device) if s.cuda_stream not in taken]
+    out = pool[:k]
+    out += [torch.cuda.Stream(device=device) for _ in range(k - len(out))]
+    return out
 
 
 def spread(streams, n):
@@ -75,7 +129,8 @@ def run_on_streams(runners, streams=None):
         return
     device = next(runners[0].model.parameters()).device
     if streams is None:
-        streams = spread(concurrent_streams(len(runners), device), len(runners))
+        streams = spread(concurrent_streams(len(runners), device) or [torch.cuda.Stream(device=device)], len(runners))
+    reserve(streams, device)        # (the chains' exact passes take their lanes from the rest)
     main = torch.cuda.current_stream(device)
     for s in streams:
         s.wait_stream(main)

@@ -162,6 +162,8 @@ typedef struct {
 } sgmcmc_step_args;
 
 int sgmcmc_abi_version(void);
+/* hash of the sources the library was built from (csrc/ + include/), as the build handed it in; "unstamped" if it did not */
+const char* sgmcmc_source_sha(void);
 const char* sgmcmc_error_string(int err);
 
 /* One transition of one parameter group: fused noise + momentum + position +

@@ -74,11 +74,13 @@ def _timed_loop(model, opt, sched, batches, num_data, step, budget_s, min_steps)
 
 
 def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperature, steps_per_cycle,
-                      budget_s=12.0, warmup=5, min_steps=20, thread_choices=(1, 2, 4, 8, 16, 32, 64, 128)):
+                      budget_s=30.0, warmup=5, min_steps=20, thread_choices=(1, 2, 4, 8, 16, 32, 64, 128), blocks=3):
     """Run the loop above on the host for about ``budget_s`` seconds with the thread count
     that is fastest for this workload (a short calibration over ``thread_choices`` first:
     tiny nets get SLOWER with more OpenMP threads, and the baseline must not be handicapped).
-    Returns dict(steps_per_s, steps, seconds, cores, calibration)."""
+    The timed sample is ``blocks`` blocks of ``budget_s / blocks`` seconds each; ``steps_per_s`` is the MEDIAN block's rate
+    (one 12 s sample ranged 17.7 - 21.1 steps/s across boxes and runs of one tree in round 5), the per-block rates are
+    returned beside it.  Returns dict(steps_per_s, steps, seconds, cores, host_cpus, cpu_model, calibration, block_steps_per_s)."""
     import os
     ncpu = os.cpu_count() or 1
     model, opt, sched = _setup(make_model, batches, num_data, lr, momentum, temperature,
@@ -99,6 +101,26 @@ def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperatur
         step += 1
         x, y = batches[step % len(batches)]
         cpu_leapfrog(model, opt, sched, x, y, step, num_data)
-    n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, budget_s, min_steps)
-    return dict(steps_per_s=n / dt, steps=n, seconds=dt, cores=best, host_cpus=ncpu,
-                calibration={str(k): round(v, 1) for k, v in calib.items()})
+    rates, n_tot, dt_tot = [], 0, 0.0
+    for _ in range(max(1, blocks)):
+        n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, budget_s / max(1, blocks),
+                                  max(1, min_steps // max(1, blocks)))
+        rates.append(n / dt)
+        n_tot, dt_tot = n_tot + n, dt_tot + dt
+    rates_sorted = sorted(rates)
+    return dict(steps_per_s=rates_sorted[len(rates_sorted) // 2], steps=n_tot, seconds=dt_tot, cores=best, host_cpus=ncpu,
+                cpu_model=cpu_model(), calibration={str(k): round(v, 1) for k, v in calib.items()},
+                block_steps_per_s=[round(r, 2) for r in rates])
+
+
+def cpu_model():
+    "the host CPU's model name (/proc/cpuinfo), for the record next to the core count"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"

@@ -66,3 +66,29 @@ def test_the_alternatives_build_passes_its_own_tests_on_this_box():
     import re
     m = re.search(r"(\d+) passed(?:, (\d+) skipped)?", tail)
     assert m and int(m.group(1)) >= 200 and not m.group(2), tail        # nothing of these files is skipped in that build
+
+
+def test_loader_refuses_a_library_built_from_other_sources(tmp_path):
+    """The binary is bound to its sources (round 6): the library exports the hash of csrc/ + include/ it was compiled
+    from, and ``_hip.lib()`` refuses one whose hash is not the tree's -- here a copy of the package in which one kernel
+    source is touched AFTER the build.  SGMCMC_ALLOW_STALE_LIB=1 turns the refusal into a warning."""
+    import shutil
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert _hip.library_sha().split("+")[0] == _hip.source_sha() != "unstamped"
+    shutil.copytree(os.path.join(root, "bnn_priors_amd"), tmp_path / "bnn_priors_amd",
+                    ignore=shutil.ignore_patterns("__pycache__", "libsgmcmc_hip_alt.so"))
+    shutil.copytree(os.path.join(root, "include"), tmp_path / "include")
+    with open(tmp_path / "bnn_priors_amd" / "csrc" / "bn_hip.inc", "a") as f:
+        f.write("\n// edited after the build\n")
+    code = ("import sys, warnings; sys.path.insert(0, %r); from bnn_priors_amd import _hip\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    try:\n        _hip.lib(); print('LOADED', len(w))\n"
+            "    except _hip.HipExtensionMissing as e:\n        print('REFUSED', 'rebuild' in str(e))\n") % str(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("SGMCMC_ALTERNATIVES", "SGMCMC_ALLOW_STALE_LIB", "PYTHONPATH")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.stdout.strip() == "REFUSED True", out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, SGMCMC_ALLOW_STALE_LIB="1"), capture_output=True,
+                         text=True, cwd=str(tmp_path))
+    assert out.stdout.strip() == "LOADED 1", out.stdout + out.stderr

@@ -27,9 +27,21 @@ def test_compact_line_is_small_and_complete():
     top, other = bench.headline_rooflines(out["roofline_kernels"])
     out["roofline"] = top
     out["roofline_mfma" if other["bound"] == "mfma" else "roofline_hbm"] = other
+    out["roofline_step"] = bench.step_roofline(out["roofline_kernels"], out["ms_per_step"])
+    out["cpu_baseline"].update(cpu_model="AMD EPYC 9575F 64-Core Processor", block_steps_per_s=[20.1, 21.2, 20.7],
+                               threads_calibration_steps_per_s={str(2 ** k): 10.0 + k for k in range(8)})
     text = bench.compact_line(out, os.path.join(ROOT, "bench_detail.json"))
     assert len(text) < 4096 and "\n" not in text
     line = json.loads(text)
+    # round 6: the headline fraction is the IN-STEP one, the isolated-launch figure beside it; the whole step against the
+    # MFMA peak; the CPU leg says what it ran on and how steady it was
+    assert line["roofline"]["frac_source"] == "in_step" and line["roofline"]["frac"] <= line["roofline"]["frac_isolated"] + 0.05
+    assert line["roofline"]["achieved"] == pytest.approx(line["roofline"]["frac"] * line["roofline"]["peak"], rel=2e-3)
+    for k in ("flops_per_step", "achieved_tflops", "peak", "frac", "launches_per_step", "gpu_busy_us"):
+        assert k in line["roofline_step"], k
+    assert 25e9 < line["roofline_step"]["flops_per_step"] < 40e9 and 0 < line["roofline_step"]["frac"] < 1
+    for k in ("cpu_model", "block_steps_per_s", "threads_calibration_steps_per_s"):
+        assert k in line["cpu_baseline"], k
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_sampler", "roofline_flat_arena",
               "cpu_baseline", "samples_per_sec", "speedup_vs_cpu", "detail", "ranks_seen"):
@@ -82,7 +94,8 @@ def test_headline_is_the_symbol_with_the_largest_time_per_step():
     assert top["us_per_step"] == pytest.approx(max(per_symbol.values()), abs=0.06)
     assert other is not None and other["bound"] != top["bound"]
     # pooled over shapes: work / time, both summed over the launches of a step
-    assert 0 < top["frac"] <= 1 and 0 < top["frac_in_step"] <= 1
+    assert 0 < top["frac"] <= 1 and top["frac_in_step"] == top["frac"] and top["frac_source"] == "in_step"
+    assert 0 < top["frac_isolated"] <= 1
 
 
 def test_committed_measurements_of_other_sources_are_marked_stale(tmp_path, monkeypatch):
@@ -96,11 +109,12 @@ def test_committed_measurements_of_other_sources_are_marked_stale(tmp_path, monk
     (fake_root / "profiles" / "in_step_us.json").write_text(json.dumps(dict(body, source_sha="0" * 16)))
     got = bench.attach_in_step([dict(rows[0])])[0]
     assert got.get("stale") is True and "frac_in_step" not in got and "in_step_us" not in got
-    (fake_root / "profiles" / "in_step_us.json").write_text(json.dumps(dict(body, source_sha=_hip.source_sha())))
+    (fake_root / "profiles" / "in_step_us.json").write_text(json.dumps(dict(body, source_sha=_hip.library_sha())))
     got = bench.attach_in_step([dict(rows[0])])[0]
     assert "stale" not in got and got["frac_in_step"] == pytest.approx(6e8 / 10e-6 / 1e12 / 157.3, rel=1e-3)
     top, _ = bench.headline_rooflines([dict(rows[0], stale=True)])
-    assert top["stale"] is True and "frac_in_step" not in top
+    assert top["stale"] is True and "frac_in_step" not in top and top["frac_source"] == "isolated"
+    assert top["frac"] == top["frac_isolated"]
 
 
 def test_gpus_flag_launches_ranks_unless_already_a_rank(monkeypatch):

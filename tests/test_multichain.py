@@ -114,3 +114,24 @@ def test_concurrent_streams_really_run_side_by_side():
     together = min(multichain._spin_time(picked, dev, 400_000, 3) for _ in range(3))
     assert together < 1.5 * alone, (alone, together)
     assert len(multichain.spread(picked, 5)) == 5
+
+
+@pytest.mark.gpu
+def test_lanes_are_distinct_streams_and_never_a_chains_main_stream(monkeypatch):
+    """multichain.lanes (round 6): the exact pass's helper streams are DISTINCT and are none of the streams reserved for a
+    chain's own launches; when the measured pool has fewer left, fresh streams make up the number instead of one stream
+    being handed out twice.  SGMCMC_STREAM_PROBE=0 hands out fresh streams without measuring."""
+    from bnn_priors_amd import multichain
+    dev = torch.device("cuda", 0)
+    mains = multichain.concurrent_streams(2, dev)
+    monkeypatch.setattr(multichain, "_reserved", {})
+    multichain.reserve(mains, dev)
+    got = multichain.lanes(3, dev, exclude=[torch.cuda.current_stream(dev)])
+    handles = [s.cuda_stream for s in got]
+    assert len(set(handles)) == 3 and not set(handles) & {s.cuda_stream for s in mains}
+    assert torch.cuda.current_stream(dev).cuda_stream not in handles
+    many = multichain.lanes(12, dev)            # more than any pool holds: still all distinct
+    assert len({s.cuda_stream for s in many}) == 12
+    monkeypatch.setenv("SGMCMC_STREAM_PROBE", "0")
+    fresh = multichain.concurrent_streams(3, dev)
+    assert len({s.cuda_stream for s in fresh}) == 3

@@ -40,7 +40,7 @@ for path in sys.argv[1:]:
         if ratio:
             rows[key]["algorithmic_bytes"] = round((float(ratio.group(1)) + float(ratio.group(2))) * 1e6)
             rows[key]["traffic_over_algorithmic"] = float(ratio.group(3))
-print(json.dumps({"source": ", ".join(sys.argv[1:]), "source_sha": _hip.source_sha(),
-                  "collected_by": "tools/pmc_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter-only passes "
+print(json.dumps({"source": ", ".join(sys.argv[1:]), "source_sha": _hip.library_sha(),
+                  "collected_by": "tools/pmc_hbm.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate counter-only passes "
                                   "with --kernel-trace) over tools/conv_pmc.py and tools/bn_pmc.py at n = 128",
                   "kernels": rows}, indent=1))

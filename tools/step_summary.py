@@ -104,7 +104,7 @@ if a.json:
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bnn_priors_amd import _hip
-    out = {"source": a.source or a.csv, "source_sha": _hip.source_sha(), "steps_averaged": n, "launches_per_step": common,
+    out = {"source": a.source or a.csv, "source_sha": _hip.library_sha(), "steps_averaged": n, "launches_per_step": common,
            "gpu_busy_us_per_step": round(busy / n / 1e3, 1),
            "collected_by": "rocprofv3 --kernel-trace over bench.py (tools/prof_workload.sh), tools/step_summary.py --json",
            "kernels": {k: {"in_step_us": round(v[1] / v[0] / 1e3, 3), "launches_per_step": round(v[0] / n, 3)}
