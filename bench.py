@@ -723,12 +723,29 @@ def _library_calls():
     return {f"{op}{list(shape)}": n for (op, shape), n in conv.LIBRARY_CALLS.items()}
 
 
+def per_rank_summary(rates, solo):
+    """min / median / max of the ranks' own steps/s in the N-rank region, rank 0's rate when it ran ALONE right before it,
+    and their ratio: what one GPU loses to its neighbours' presence (host contention, shared power and cooling) --
+    the one-run stand-in for a scaling curve; SCALE_rNN.json's per-N runs are the curve itself."""
+    r = sorted(rates)
+    out = {"min": round(r[0], 2), "median": round(statistics.median(r), 2), "max": round(r[-1], 2), "ranks": len(r),
+           "solo_rank0": None if solo is None else round(solo, 2), "efficiency_vs_solo": None}
+    if solo:
+        out["efficiency_vs_solo"] = round(statistics.median(r) / solo, 4)
+    return out
+
+
+def cpu_shares(cpus, local_world):
+    "the CPUs of every local rank: contiguous, disjoint, equal shares of the sorted list (the remainder stays unused)"
+    cpus = sorted(cpus)
+    per = max(1, len(cpus) // max(1, local_world))
+    return [cpus[r * per:(r + 1) * per] or cpus for r in range(local_world)]
+
+
 def pin_process(local, local_world):
     "one rank = one contiguous share of the host's CPUs (8 drivers + 8 HIP runtimes must not migrate / collide)"
     try:
-        cpus = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cpus) // max(1, local_world))
-        mine = cpus[local * per:(local + 1) * per] or cpus
+        mine = cpu_shares(os.sched_getaffinity(0), local_world)[local]
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(8, len(mine))))
         return len(mine)
@@ -848,7 +865,7 @@ def compact_line(out, detail_path):
     cfg = out["config"]
     line["config"] = {"workload": cfg["workload"][:300], "params": cfg["params"], "chains": cfg["chains"],
                       "step_path": cfg["step_path"][:200]}
-    for k in ("ranks_seen", "backend"):
+    for k in ("ranks_seen", "backend", "per_rank_steps_per_s"):
         if k in out:
             line[k] = out[k]
     if "devices" in out:
@@ -1018,6 +1035,24 @@ def main():
         dist.broadcast(nb, src=0)
         n_blocks = int(nb.item())
         dist.barrier()
+    # Multi-rank runs: rank 0 first times the same blocks ALONE (the other ranks wait at a barrier, their GPUs idle) -- the
+    # per-GPU rate that the N-rank region's per-rank rates are set against (efficiency_vs_solo in the line; the driver
+    # computes its own scaling efficiency from the per-N values of separate runs)
+    solo_ms = None
+    if distributed and world > 1:
+        if rank == 0:
+            torch.cuda.synchronize(device)
+            sm = [torch.cuda.Event(enable_timing=True)]
+            sm[0].record(stream)
+            for _ in range(n_blocks):
+                step = run(K, step)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream)
+                sm.append(ev)
+            runner._drain_rows()
+            torch.cuda.synchronize(device)
+            solo_ms = statistics.median(a.elapsed_time(b) for a, b in zip(sm[:-1], sm[1:]))
+        dist.barrier()
     torch.cuda.synchronize(device)
     marks = [torch.cuda.Event(enable_timing=True)]
     marks[0].record(stream)
@@ -1034,7 +1069,12 @@ def main():
     wall = time.perf_counter() - t0
     block_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
     med_ms = statistics.median(block_ms)
+    per_rank = None
     if distributed:
+        mine = torch.tensor([med_ms], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [K / (float(t.item()) * 1e-3) for t in every]          # steps/s of every rank's median block
         t = torch.tensor([med_ms, wall], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         med_ms, wall = t[0].item(), t[1].item()
@@ -1151,6 +1191,8 @@ def main():
     }
     if pinned_cpus is not None:
         out["config"]["cpus_per_rank"] = pinned_cpus
+    if per_rank is not None:
+        out["per_rank_steps_per_s"] = per_rank_summary(per_rank, None if solo_ms is None else K / (solo_ms * 1e-3))
     if samples is not None and args.samples >= 10:
         out["samples_per_sec"] = {"value": round(world * samples, 3), "per_chain": round(samples, 3),
                                   "cycles_timed": args.samples,

@@ -37,7 +37,7 @@ WITH_LOG_PRIOR = 128
 DEFER_FINALIZE = 256
 INLINE_PRIOR = 512
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_LAPLACE, PRIOR_STUDENT_T, PRIOR_CAUCHY, PRIOR_GENNORM = 0, 1, 2, 3, 4, 5
-PRIOR_GAMMA_SOFTPLUS, PRIOR_UNIFORM_CDF, PRIOR_HALFCAUCHY_SOFTPLUS = 6, 7, 8
+PRIOR_GAMMA_SOFTPLUS, PRIOR_UNIFORM_CDF, PRIOR_HALFCAUCHY_SOFTPLUS, PRIOR_IMPROPER_SOFTPLUS = 6, 7, 8, 9
 PRIOR_HAS_LINKS, PRIOR_FULL = 1, 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",

@@ -330,7 +330,7 @@ __device__ __forceinline__ double prior_log_norm(const sgmcmc_segment& s, double
 // (out of line: rare path with heavy double-precision math; inlined it costs every caller ~80 VGPRs)
 __device__ __attribute__((noinline)) double hyper_value(const sgmcmc_segment& h, double s, double& dxds) {
   const double sig = 1.0 / (1.0 + exp(-s)), sp = s > 30.0 ? s : log1p(exp(s));
-  if (h.prior_kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS) { dxds = sig; return sp; }
+  if (h.prior_kind == SGMCMC_PRIOR_GAMMA_SOFTPLUS || h.prior_kind == SGMCMC_PRIOR_IMPROPER_SOFTPLUS) { dxds = sig; return sp; }
   if (h.prior_kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) { dxds = sig * h.prior_loc; return sp * h.prior_loc; }
   // UNIFORM_CDF: low + (high - low) Phi(s)
   const double w = h.prior_scale - h.prior_loc;
@@ -347,6 +347,7 @@ __device__ __attribute__((noinline)) double hyper_prior_dlogp(int kind, double l
     l = loc * log(scale) - lgamma(loc) + (loc - 1.0) * log(x) - scale * x;
     return ((loc - 1.0) / x - scale) * sig;
   }
+  if (kind == SGMCMC_PRIOR_IMPROPER_SOFTPLUS) { l = 0.0; return 0.0; }      // no density of its own
   if (kind == SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS) {        // loc = multiplier, scale = gamma
     const double z = x * loc / scale;
     l = log(2.0 / (3.14159265358979323846 * scale)) - log1p(z * z);

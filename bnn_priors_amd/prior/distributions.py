@@ -1,7 +1,8 @@
 """Distributions the prior modules need beyond ``torch.distributions``.
 
 ``GeneralizedNormal(loc, scale, beta)``: density  beta / (2 scale Gamma(1/beta)) * exp(-(|x - loc| / scale)^beta)
-(reference: bnn_priors/prior/distributions.py:15-98).  Sampling goes through ``scipy.stats.gennorm`` seeded from
+(reference: bnn_priors/prior/distributions.py:15-98).  ``DoubleGamma(concentration, rate)``: a Gamma density on |x|,
+halved, with a random sign when sampled (distributions.py:97-112).  Sampling goes through ``scipy.stats.gennorm`` seeded from
 torch's global generator, so a run under ``torch.manual_seed`` draws what the reference draws.
 """
 import torch
@@ -9,7 +10,7 @@ from torch.distributions import constraints
 from torch.distributions.distribution import Distribution
 from torch.distributions.utils import broadcast_all
 
-__all__ = ("GeneralizedNormal",)
+__all__ = ("GeneralizedNormal", "DoubleGamma")
 
 
 class GeneralizedNormal(Distribution):
@@ -46,3 +47,21 @@ class GeneralizedNormal(Distribution):
         seed = torch.randint(2 ** 32, ()).item()     # one draw from torch's generator per call
         shape = list(torch.Size(sample_shape) + self.loc.size())
         return torch.tensor(frozen.rvs(shape, random_state=seed), dtype=self.loc.dtype, device=self.loc.device)
+
+
+class DoubleGamma(torch.distributions.Gamma):
+    "density Gamma(|x|; concentration, rate) / 2 on the real line"
+    mean = 0.
+
+    @property
+    def variance(self):
+        return self.concentration * (1 + self.concentration) / self.rate.pow(2)
+
+    def rsample(self, sample_shape=torch.Size()):
+        x = super().rsample(sample_shape)
+        sign = torch.randint(0, 2, x.size(), device=x.device, dtype=x.dtype).mul_(2).sub_(1)
+        return x * sign
+
+    def log_prob(self, value):
+        import math
+        return super().log_prob(value.abs()) - math.log(2)

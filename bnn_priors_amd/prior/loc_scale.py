@@ -10,7 +10,8 @@ import torch.distributions as td
 from .base import Prior
 from .distributions import GeneralizedNormal
 
-__all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "GenNorm", "LogNormal", "Improper", "get_prior",
+__all__ = ("LocScale", "Normal", "Laplace", "Cauchy", "StudentT", "GenNorm", "LogNormal", "Improper", "PositiveImproper",
+           "get_prior",
            "FUSED_NONE", "FUSED_NORMAL", "FUSED_LAPLACE", "FUSED_STUDENT_T", "FUSED_CAUCHY", "FUSED_GENNORM")
 
 FUSED_NONE, FUSED_NORMAL, FUSED_LAPLACE, FUSED_STUDENT_T, FUSED_CAUCHY, FUSED_GENNORM = 0, 1, 2, 3, 4, 5
@@ -75,28 +76,55 @@ class Improper(Normal):
         return 0.0
 
 
+class PositiveImproper(Improper):
+    """value = softplus(p), no density: the learnable scale (shape parameter, lengthscale) of the empirical-Bayes priors
+    (reference: prior/loc_scale.py:100-103, used by prior/empirical_bayes.py).  As the one-element scale of a Normal /
+    Laplace / Student-t prior it is a hyper-prior kind of the HIP hook (SGMCMC_PRIOR_IMPROPER_SOFTPLUS: the chain rule
+    through softplus, nothing of its own)."""
+    fused_kind = 9      # _hip.PRIOR_IMPROPER_SOFTPLUS
+
+    def forward(self):
+        import torch.nn.functional as F
+        return F.softplus(self.p)
+
+    def fused_spec(self):
+        if self.p.numel() != 1:
+            return None
+        return self.fused_kind, 0.0, 1.0, 0.0
+
+
 def _table():
-    from . import hierarchical as H, mixture as M, transformed as T
+    from . import correlated as C, empirical_bayes as E, hierarchical as H, mixture as M, transformed as T
     return {"gaussian": Normal, "laplace": Laplace, "student-t": StudentT, "cauchy": Cauchy,
             "improper": Improper, "gennorm": GenNorm,
-            # by name, through autograd (Potential.leftover) -- the reference's table has them (prior/mixture.py:17-50):
-            "lognormal": LogNormal, "uniform": T.Uniform, "mixture": M.Mixture, "scale_mixture": M.ScaleMixture,
             "gaussian_gamma": H.NormalGamma, "gaussian_uniform": H.NormalUniform, "horseshoe": H.Horseshoe,
             "laplace_gamma": H.LaplaceGamma, "laplace_uniform": H.LaplaceUniform,
             "student-t_gamma": H.StudentTGamma, "student-t_uniform": H.StudentTUniform,
-            "gennorm_uniform": H.GenNormUniform}
+            # learnable scale without a hyper-prior (prior/empirical_bayes.py:24-58): Normal and Laplace in the HIP hook
+            # (scale linked to a PositiveImproper segment), Student-t / generalised normal (their df / beta is learnable
+            # too) through autograd
+            "gaussian_empirical": E.NormalEmpirical, "laplace_empirical": E.LaplaceEmpirical,
+            "student-t_empirical": E.StudentTEmpirical, "gennorm_empirical": E.GenNormEmpirical,
+            # by name, through autograd (Potential.leftover) -- the rest of the reference's table (prior/mixture.py:17-50):
+            "lognormal": LogNormal, "uniform": T.Uniform, "mixture": M.Mixture, "scale_mixture": M.ScaleMixture,
+            "scale_mixture_empirical": M.ScaleMixtureEmpirical, "gennorm_uniform": H.GenNormUniform,
+            "convcorrnormal": C.ConvCorrelatedNormal, "convcorrnormal_fitted_ls": C.ConvCorrelatedNormal,
+            "convcorrnormal_empirical": E.ConvCorrNormalEmpirical, "convcorrnormal_gamma": C.ConvCorrNormalGamma,
+            "fixedcov_normal": C.FixedCovNormal, "fixedcov_gennorm": C.FixedCovGenNorm,
+            "datadrivencorrnormal": Normal, "datadrivencorrdoublegamma": T.DoubleGamma}
 
 
 def get_prior(name):
-    """Name -> class (reference table: prior/mixture.py:17-50).  Element-wise families and hierarchical scales are
-    differentiated by the HIP prior hook; ``lognormal``, ``uniform`` (as a tensor's prior), ``mixture`` and
-    ``scale_mixture`` are built as the reference builds them and stay in autograd (``Potential.leftover``, with a
-    one-time notice).  The correlated / data-driven / empirical-Bayes entries are out of scope."""
+    """Name -> class: ALL 31 names of the reference's table (prior/mixture.py:17-50).  Element-wise families, hierarchical
+    scales and the learnable scales of ``gaussian_empirical`` / ``laplace_empirical`` are differentiated by the HIP prior
+    hook; everything else -- mixtures, the correlated / fixed-covariance convolution priors, the double Gamma, families
+    whose shape parameter is learnable -- is built as the reference builds it and stays in autograd
+    (``Potential.leftover``, with a one-time notice; such a model's step is not captured into a hipGraph)."""
     if isinstance(name, type) and issubclass(name, Prior):
         return name
     table = _table()
     try:
         return table[name]
     except KeyError:
-        raise KeyError(f"prior '{name}' is not built by this package (correlated / data-driven / empirical-Bayes "
-                       f"families are out of scope); available: {sorted(table)}") from None
+        raise KeyError(f"prior '{name}' is not in the reference's table (prior/mixture.py:17-50); available: "
+                       f"{sorted(table)}") from None

@@ -22,13 +22,14 @@ import torch.distributions as td
 from .base import Prior
 from .loc_scale import LocScale, get_prior
 
-__all__ = ("Mixture", "ScaleMixture")
+__all__ = ("Mixture", "ScaleMixture", "ScaleMixtureEmpirical")
 
 # abbreviation -> table name (mixture.py:100-126)
 ABBREVIATIONS = {"g": "gaussian", "ln": "lognormal", "l": "laplace", "c": "cauchy", "s": "student-t", "u": "uniform",
                  "i": "improper", "gg": "gaussian_gamma", "gu": "gaussian_uniform", "h": "horseshoe",
                  "lg": "laplace_gamma", "lu": "laplace_uniform", "sg": "student-t_gamma", "su": "student-t_uniform",
-                 "gn": "gennorm", "gnu": "gennorm_uniform"}
+                 "gn": "gennorm", "gnu": "gennorm_uniform", "ge": "gaussian_empirical", "le": "laplace_empirical",
+                 "se": "student-t_empirical", "gne": "gennorm_empirical"}
 
 
 def _as_component(comp, p):
@@ -90,3 +91,19 @@ class ScaleMixture(Mixture):
         # generalised normal then) -- views of ``p`` that are part of every stored sample and of no density.
         Mixture.__init__(self, shape, loc, scale)
         self._install([get_prior(base_dist)(shape, loc, s) for s in self.scales])
+
+
+class ScaleMixtureEmpirical(Mixture):
+    """``ScaleMixture`` whose five scales are learnable (softplus of a parameter without a prior, initialised at
+    scale x {1/9, 1/3, 1, 3, 9}): reference prior/mixture.py:154-178.  The scales are sampled parameters
+    ``component_<k>.scale.p``; autograd."""
+    def __init__(self, shape, loc, scale, base_dist="gaussian", scales=None):
+        from .loc_scale import PositiveImproper
+        from .transformed import inv_softplus
+        self.scales = [scale / 9, scale / 3, scale, scale * 3, scale * 9] if scales is None else scales
+        Mixture.__init__(self, shape, loc, scale)          # (the default mixture first, as ScaleMixture and the reference do)
+        hypers = [PositiveImproper(shape=[], loc=s, scale=1.) for s in self.scales]
+        for h, s in zip(hypers, self.scales):
+            with torch.no_grad():
+                h.p.data = inv_softplus(torch.tensor(s))
+        self._install([get_prior(base_dist)(shape, loc, h) for h in hypers])

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from .base import Prior
 
-__all__ = ("Uniform", "Gamma", "HalfCauchy", "inv_softplus")
+__all__ = ("Uniform", "Gamma", "HalfCauchy", "DoubleGamma", "inv_softplus")
 
 FUSED_GAMMA_SOFTPLUS, FUSED_UNIFORM_CDF, FUSED_HALFCAUCHY_SOFTPLUS = 6, 7, 8
 
@@ -101,3 +101,22 @@ class HalfCauchy(Prior):
         if not (_plain(self.scale) and isinstance(self.multiplier, (int, float))):
             return None
         return self.fused_kind, float(self.multiplier), float(self.scale), 0.0
+
+
+class DoubleGamma(Prior):
+    """p - loc ~ DoubleGamma(concentration, rate = 1 / scale): the element-wise marginal of the reference's data-driven
+    prior ``datadrivencorrdoublegamma`` (prior/transformed.py:83-95).  Not a family of the HIP hook: autograd."""
+    fused_kind = None
+
+    def __init__(self, shape, loc, scale, concentration):
+        super().__init__(shape, loc=loc, scale=scale, concentration=concentration)
+
+    def _dist(self, loc, scale, concentration):
+        from .distributions import DoubleGamma as D
+        return D(concentration=concentration, rate=1 / scale)
+
+    def _draw(self, shape):
+        return super()._draw(shape) + self.loc
+
+    def log_prob(self):
+        return self._dist_obj().log_prob(self.p - self.loc).sum()

@@ -74,12 +74,15 @@ enum {
  *   UNIFORM_CDF        value x = low + (high - low) Phi(s), low = prior_loc, high = prior_scale: log p = -log(high-low)
  *   HALFCAUCHY_SOFTPLUS value x = softplus(s) * multiplier (prior_loc) ~ HalfCauchy(scale = prior_scale), the density
  *                      evaluated AT x: log p = log(2 / (pi g)) - log(1 + (x/g)^2)
+ *   IMPROPER_SOFTPLUS  value x = softplus(s), NO density (log p = 0, no gradient of its own): the learnable scale of the
+ *                      empirical-Bayes priors (prior/loc_scale.py:100-103 under prior/empirical_bayes.py:24-38)
  * A weight segment whose scale_link > 0 takes its scale from the VALUE of hyper segment scale_link - 1 (one element)
  * at launch time instead of prior_scale; sgmcmc_prior_grad then also adds
  * -(1/N) (d/dscale sum_j log p(theta_j)) dx/ds to the hyper segment's gradient (flags & SGMCMC_PRIOR_HAS_LINKS). */
 enum { SGMCMC_PRIOR_NONE = 0, SGMCMC_PRIOR_NORMAL = 1, SGMCMC_PRIOR_LAPLACE = 2,
        SGMCMC_PRIOR_STUDENT_T = 3, SGMCMC_PRIOR_CAUCHY = 4, SGMCMC_PRIOR_GENNORM = 5,
-       SGMCMC_PRIOR_GAMMA_SOFTPLUS = 6, SGMCMC_PRIOR_UNIFORM_CDF = 7, SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS = 8 };
+       SGMCMC_PRIOR_GAMMA_SOFTPLUS = 6, SGMCMC_PRIOR_UNIFORM_CDF = 7, SGMCMC_PRIOR_HALFCAUCHY_SOFTPLUS = 8,
+       SGMCMC_PRIOR_IMPROPER_SOFTPLUS = 9 };
 /* flags of sgmcmc_prior_grad: some segment is linked to a hyper segment / some segment's kind is beyond CAUCHY
  * (without either the lean kernel for the four constant-scale families is launched) */
 enum { SGMCMC_PRIOR_HAS_LINKS = 1, SGMCMC_PRIOR_FULL = 2 };

@@ -138,6 +138,25 @@ def test_gpus_flag_launches_ranks_unless_already_a_rank(monkeypatch):
     assert bench.self_launch(types.SimpleNamespace(gpus=2, backend="nccl")) is None  # already a rank: run the bench
 
 
+def test_eight_ranks_get_disjoint_cpu_shares_and_a_per_rank_summary():
+    """one-command 8-GPU readiness (round 6): `python bench.py --gpus 8` deals the host's CPUs into 8 disjoint contiguous
+    shares (256 CPUs -> 32 each), refuses the RCCL path loudly with fewer than 8 devices (test above), and its line
+    carries every rank's own rate next to rank 0's solo rate."""
+    shares = bench.cpu_shares(range(256), 8)
+    assert [len(s) for s in shares] == [32] * 8 and sorted(c for s in shares for c in s) == list(range(256))
+    assert all(s == list(range(s[0], s[0] + 32)) for s in shares)
+    assert [len(s) for s in bench.cpu_shares(range(10), 4)] == [2, 2, 2, 2]          # (the remainder stays unused)
+    assert bench.cpu_shares([3], 2) == [[3], [3]]                                    # fewer CPUs than ranks: shared, never empty
+    got = bench.per_rank_summary([1200.0, 1180.0, 1210.0, 1190.0, 1205.0, 1195.0, 1185.0, 1215.0], solo=1240.0)
+    assert got["min"] == 1180.0 and got["max"] == 1215.0 and got["ranks"] == 8 and got["solo_rank0"] == 1240.0
+    assert got["median"] == 1197.5 and got["efficiency_vs_solo"] == round(1197.5 / 1240.0, 4)
+    assert bench.per_rank_summary([5.0], None)["efficiency_vs_solo"] is None
+    out = _full_record()
+    out["n_gpus"] = out["ranks_seen"] = 8
+    out["per_rank_steps_per_s"] = got
+    assert json.loads(bench.compact_line(out, None))["per_rank_steps_per_s"] == got
+
+
 def _run_bench(*flags, timeout=600):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -162,6 +181,9 @@ def test_gpus_2_over_gloo_starts_two_ranks_by_itself(tmp_path):
     assert [d["rank"] for d in line["devices"]] == [0, 1] and [d["local_rank"] for d in line["devices"]] == [0, 1]
     assert line["exchange"]["ensemble_matches_single_process"] and line["exchange"]["gather_order_checked"]
     assert line["config"]["chains"] == 2 and line["value"] > 0
+    pr = line["per_rank_steps_per_s"]          # every rank's own rate, and rank 0's when it ran alone right before
+    assert pr["ranks"] == 2 and 0 < pr["min"] <= pr["median"] <= pr["max"] and pr["solo_rank0"] > 0
+    assert 0 < pr["efficiency_vs_solo"] < 1.5
     full = json.loads(detail.read_text())
     assert full["value"] == line["value"] and "timing" in full and full["exchange"]["chains"] == 2
 
