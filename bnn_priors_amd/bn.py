@@ -18,7 +18,7 @@ from . import _hip
 from . import bnlink as _bnlink
 from . import conv as _conv
 
-ENABLED = os.environ.get("SGMCMC_BN", "1") != "0"
+ENABLED = True          # (module attribute, not an environment switch)
 
 
 def supported(x, weight, bias, training, momentum):
@@ -281,8 +281,8 @@ class _BNTrain(torch.autograd.Function):
 
 
 # ---- relu(BN(x) + BN_s(r)): the last BatchNorm of a down-sampling block with the shortcut's BatchNorm applied on the fly
-# (csrc/bn_hip.inc apply_dual_kernel).  SGMCMC_BN_DUAL=0 restores the two operators (A/B runs, the tests' cross-check).
-DUAL = os.environ.get("SGMCMC_BN_DUAL", "1") != "0"
+# (csrc/bn_hip.inc apply_dual_kernel).  ``DUAL = False`` restores the two operators (the tests' cross-check).
+DUAL = True
 
 
 def dual_supported(x, stats, r, r_stats, bn, bn_s):

@@ -16,7 +16,7 @@ Nothing here launches anything; reference semantics: BatchNorm2d's backward redu
 models/google_resnet.py:34-43 (inference.py:215-223)."""
 import os
 
-ENABLED = os.environ.get("SGMCMC_BN_EPILOGUE_SUMS", "1") != "0"
+ENABLED = True          # (module attribute, not an environment switch)
 # Round 4: a launch that leaves the sums also STORES the gradient masked, dz = dx * [out > 0] (``mask_dx`` of
 # sgmcmc_conv_bwd_epilogue: it holds the mask for the sums anyway).  The gradient of a BatchNorm + ReLU output has two
 # kinds of consumers -- the BatchNorm's dx launch and the shortcut add of the residual block before -- and both form

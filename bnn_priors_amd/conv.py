@@ -44,8 +44,8 @@ def library_path(op, x):
 
 
 SHAPES = {(16, 32), (32, 16), (64, 8)}      # (channels, image side)
-ENABLED = os.environ.get("SGMCMC_CONV", "1") != "0"
-DEFER_REDUCE = os.environ.get("SGMCMC_CONV_DEFER", "1") != "0"
+ENABLED = True          # (module attribute, not an environment switch)
+DEFER_REDUCE = True
 # the persistent kernels on prepared weight fragments (csrc/conv2_hip.inc): double-buffered workgroups over a stream of
 # 4-row items.  WHERE THEY RUN: launches that carry several minibatches (``persistent()`` below: the grouped exact
 # full-data pass, graphed.py) -- 10-20 % faster per launch at 512 images (tools/conv_lab), the googleresnet pass 190 ->
@@ -58,8 +58,7 @@ PERSISTENT = os.environ.get("SGMCMC_CONV_PERSISTENT", "0") == "1"
 
 # ... and, per trunk stage, for the BACKWARD launch alone (forward on the default kernels, so the BatchNorm that follows
 # reads the default statistics slices): "32x16,64x8" style list of (channels x side) -- an A/B switch of round 4
-PERSISTENT_BWD = {tuple(int(v) for v in item.split("x"))
-                  for item in os.environ.get("SGMCMC_CONV_PERSISTENT_BWD", "").split(",") if item}
+PERSISTENT_BWD = set()          # (module attribute, not an environment switch)
 
 
 def persistent_bwd(c, hw):
@@ -325,8 +324,8 @@ def frag_backward(lib, x, w, dy, defer, add=None, sums_for=None):
 
 
 # launches that carry G minibatches (bn.grouped): every weight-gradient workgroup of the trunk's 3x3 convolutions walks G
-# times as many items, so a pass leaves the slabs of ONE minibatch (SGMCMC_WRW_GROUP_MULT=0: G times as many slabs)
-WRW_GROUP_MULT = os.environ.get("SGMCMC_WRW_GROUP_MULT", "1") != "0"
+# times as many items, so a pass leaves the slabs of ONE minibatch (``WRW_GROUP_MULT = False``: G times as many slabs)
+WRW_GROUP_MULT = True
 
 
 def _group_imgs(n):
@@ -484,7 +483,7 @@ class _Conv3x3(torch.autograd.Function):
 # EvalBn): the BatchNorm is a per-channel affine map of the accumulator tile, so its launch, the convolution's output
 # tensor and the read of it disappear from every test-set forward; the bits of ``conv3x3`` followed by ``bn.bn_eval``.
 # SGMCMC_CONV_BN_EVAL=0 restores the two launches (A/B, the tests' cross-check).
-CONV_BN_EVAL = os.environ.get("SGMCMC_CONV_BN_EVAL", "1") != "0"
+CONV_BN_EVAL = True
 
 
 def conv_bn_eval_supported(x, w, bias, conv_args, bn):
@@ -722,8 +721,8 @@ def conv_first(x, w):
 
 
 # ---- the first layer with its tail (csrc/conv_down_hip.inc, convfirst::fwd_pool_kernel / wrw_pool_kernel) -----------
-# SGMCMC_CONV_POOL=0 restores conv -> bias_relu_pool as two operators (A/B runs, and the tests' cross-check).
-CONV_POOL = os.environ.get("SGMCMC_CONV_POOL", "1") != "0"
+# ``CONV_POOL = False`` restores conv -> bias_relu_pool as two operators (the tests' cross-check).
+CONV_POOL = True
 
 
 def first_pool_supported(x, w, bias, stride, padding, dilation, groups):

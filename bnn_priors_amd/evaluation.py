@@ -49,7 +49,7 @@ class _NotBatchable(Exception):
 # this package's kernels -- a captured forward per 1,024 rows, ``load_state_dict`` per sample -- is 3-4x faster for all
 # three BASELINE nets (10 samples x 10,000 rows, tools/eval_probe.py: googleresnet 141 vs 427 ms, convnet 24 vs 71,
 # densenet 15 vs 58), needs no MIOpen kernel search (1.4-5 s on first use) and gives the per-epoch evaluation's bits.
-BATCHED = os.environ.get("SGMCMC_EVAL_BATCHED", "0") == "1"
+BATCHED = False          # (module attribute, not an environment switch: tests set it)
 SAMPLE_GROUP = 32       # samples per grouped forward: bounds the activation memory at E_group * batch images
 
 
@@ -124,11 +124,11 @@ def _predictive_tables_batched(model, dataloader_test, samples, labels, E, C):
 # ``_GraphedLogits`` captures ``model.net(x)`` (eval mode: this package's convolution kernels, the running-statistics
 # BatchNorm kernel, the fused head) on a static input batch once per (model, batch shape) and replays it per batch;
 # ``load_state_dict`` writes into the parameters' own storage, so the graph sees every sample.
-EVAL_GRAPH = os.environ.get("SGMCMC_EVAL_GRAPH", "1") != "0"
+EVAL_GRAPH = True
 
 
 # rows per evaluation forward (0: the loader's own batches)
-EVAL_ROWS = int(os.environ.get("SGMCMC_EVAL_ROWS", "1024"))
+EVAL_ROWS = 1024
 
 
 def _resident_tensors(dataloader):

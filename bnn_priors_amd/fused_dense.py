@@ -86,7 +86,7 @@ class FusedDenseLeapfrog(_ReportSlots):
         # three direct launches with by-value arguments vs replaying a captured graph
         self.direct = (os.environ.get("SGMCMC_DENSE_DIRECT", "1") == "1") if direct is None else direct
         # forward/backward as two launches over 4x more workgroups (csrc/mlp_hip.inc, 'two-launch split')
-        self.split = os.environ.get("SGMCMC_DENSE_SPLIT", "1") == "1"
+        self.split = True
         self.pot, self.opt, self.eng = potential, optimizer, optimizer.engine
         self.lib = _hip.lib()
         eng, dev = self.eng, optimizer.engine.device

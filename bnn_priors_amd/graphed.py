@@ -454,8 +454,8 @@ def pick_group(n_full, rows, lanes, want=None):
             best, best_key = g, key
     return best
 # a group's G minibatches gathered (+ cropped / flipped) into the lane's static input by ONE launch instead of G
-GROUP_GATHER = os.environ.get("SGMCMC_EXACT_GROUP_GATHER", "1") != "0"
-EXACT_PERSISTENT = os.environ.get("SGMCMC_EXACT_PERSISTENT", "1") != "0"     # grouped bodies on the persistent convolutions
+GROUP_GATHER = True
+EXACT_PERSISTENT = True     # grouped bodies on the persistent convolutions
 LOG_CAPACITY = 512        # minibatches whose BatchNorm statistics fit in the log before it is replayed and reused
 
 

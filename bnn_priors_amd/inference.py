@@ -144,7 +144,7 @@ class LazyBatch:
 
 
 # minibatches handed to a captured step as LazyBatch objects (one launch between two replays); 0: gathered tensors
-LAZY_BATCHES = os.environ.get("SGMCMC_LAZY_BATCH", "1") != "0"
+LAZY_BATCHES = True          # (module attribute, not an environment switch)
 
 
 class _BatchSource:

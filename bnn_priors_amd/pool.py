@@ -12,7 +12,7 @@ from . import _hip
 from . import bnlink as _bnlink
 from . import conv as _conv
 
-ENABLED = os.environ.get("SGMCMC_POOL", "1") != "0"
+ENABLED = True          # (module attribute, not an environment switch)
 
 
 def supported(x, bias):
@@ -114,7 +114,7 @@ def _reduce_rows(slabs, out, defer):
 # tagged logits and seeds autograd with the stashed gradient; ``_PoolLinear.backward`` hands out what the launch
 # already produced.  Three launches at the launch floor become one; any other use of the logits (another loss, a
 # temperature, other labels) takes the separate kernels as before.
-FUSED_HEAD = os.environ.get("SGMCMC_FUSED_HEAD", "1") != "0"
+FUSED_HEAD = True
 _head = {"spec": None, "last": None, "counted": False}
 
 

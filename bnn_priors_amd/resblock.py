@@ -32,14 +32,12 @@ from . import bn as _bn
 from . import bnlink as _bnlink
 from . import conv as _conv
 
-ENABLED = os.environ.get("SGMCMC_BLOCK", "1") != "0"
+ENABLED = True          # (module attribute, not an environment switch)
 # (channels, side) for which the BatchNorm backward is formed inside the convolution-gradient launch.  Measured on
 # MI355X (profiles/): 32 @ 16x16 and 64 @ 8x8 gain 1-5 us per pair over bwd_dx + conv3x3_bwd; at 16 @ 32x32 the three
 # 8 MB operand tensors staged by BOTH the data- and the weight-gradient workgroups cost 4 us more than the extra
 # launch saves, so that shape keeps the two-launch BatchNorm backward (and only fuses the shortcut's add).
-FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") == "" else \
-    {tuple(int(v) for v in item.split("x")) for item in os.environ["SGMCMC_BLOCK_FUSED"].split(",")
-     if item and item != "none"}
+FUSED_BN_BWD = {(32, 16), (64, 8)}          # (module attribute: only consulted when SGMCMC_BLOCK_EPILOGUE_SUMS=0)
 # The route that replaced it (default): the BatchNorm backward's SUMS come out of the epilogue of the
 # convolution-gradient launch that produces the BatchNorm's incoming gradient (``sgmcmc_conv3x3_bwd_ex``), so a
 # BatchNorm backward is the dx launch alone and a block's backward is four launches whatever the shape:
@@ -49,7 +47,7 @@ FUSED_BN_BWD = {(32, 16), (64, 8)} if os.environ.get("SGMCMC_BLOCK_FUSED", "") =
 EPILOGUE_SUMS = os.environ.get("SGMCMC_BLOCK_EPILOGUE_SUMS", "1") != "0"
 if not EPILOGUE_SUMS and FUSED_BN_BWD and not _hip.ALTERNATIVES:
     raise RuntimeError("SGMCMC_BLOCK_EPILOGUE_SUMS=0 with fused shapes selects sgmcmc_conv3x3_bn_bwd, a measured "
-                       "alternative: build and load the library with SGMCMC_ALTERNATIVES=1 (or set SGMCMC_BLOCK_FUSED=none)")
+                       "alternative: build and load the library with SGMCMC_ALTERNATIVES=1")
 
 
 def supported(x, conv1, bn1, conv2, bn2):

@@ -92,3 +92,28 @@ def test_loader_refuses_a_library_built_from_other_sources(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, SGMCMC_ALLOW_STALE_LIB="1"), capture_output=True,
                          text=True, cwd=str(tmp_path))
     assert out.stdout.strip() == "LOADED 1", out.stdout + out.stderr
+
+
+def test_the_product_carries_twelve_documented_switches_and_no_lab_macros():
+    """Round 6 pruned the lab out of the product: the package reads at most 12 SGMCMC_* environment variables, every one
+    of them is listed in INTEGRATION.md's table, and the convolution kernels' source carries no A/B build macro any more
+    (csrc/conv_hip.inc: only the lab-only SGMCMC_STAMPS; the whole csrc/: SGMCMC_WT_STORES, SGMCMC_SOURCE_SHA,
+    SGMCMC_ALTERNATIVES besides)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "bnn_priors_amd")
+    env = set()
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                with open(os.path.join(d, f)) as fh:
+                    env |= set(re.findall(r'environ(?:\.get\(|\[)\s*"(SGMCMC_[A-Z0-9_]+)"', fh.read()))
+    assert 0 < len(env) <= 12, sorted(env)
+    with open(os.path.join(root, "INTEGRATION.md")) as fh:
+        doc = fh.read()
+    assert all(f"`{v}`" in doc for v in env), sorted(v for v in env if f"`{v}`" not in doc)
+    macros = {}
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        with open(os.path.join(pkg, "csrc", f)) as fh:
+            macros[f] = set(re.findall(r"^#\s*if(?:n?def)?\s+(?:defined\s*\(\s*)?(SGMCMC_[A-Z0-9_]+)", fh.read(), re.M))
+    assert macros["conv_hip.inc"] <= {"SGMCMC_STAMPS"}, macros["conv_hip.inc"]
+    assert set().union(*macros.values()) <= {"SGMCMC_STAMPS", "SGMCMC_WT_STORES", "SGMCMC_SOURCE_SHA", "SGMCMC_ALTERNATIVES"}, macros

@@ -33,6 +33,39 @@ def test_oracle_properties():
     assert np.array_equal((out == 0).any(axis=(1, 2, 3)), (dx != 0) | (dy != 0))
 
 
+def _semantics_fixture():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_semantics.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_reproduces_the_hand_computed_crop_and_flip_fixture():
+    """tests/golden/augment_semantics.json: RandomCrop(padding) then RandomHorizontalFlip (cifar.py:158-159) written out
+    by hand on a 4 x 4 image -- offset sign convention, zero fill, crop BEFORE flip, flip orientation.  The numpy
+    restatement must give those arrays for the recorded (row, draw); the kernel is held to the same arrays below."""
+    fx = _semantics_fixture()
+    data = np.asarray(fx["images"], dtype=np.float32)[:, None]          # [2, 1, 4, 4]
+    for case in fx["cases"]:
+        dx, dy, fl = ref.decisions(np.array([case["row"]]), fx["seed"], fx["stream"], case["draw"], fx["pad"], True)
+        assert (int(dx[0]), int(dy[0]), bool(fl[0])) == (case["dx"], case["dy"], case["flipped"]), case["name"]
+        got = ref.gather(data, [case["row"]], fx["seed"], fx["stream"], case["draw"], fx["pad"], True)
+        assert np.array_equal(got[0, 0], np.asarray(case["out"], dtype=np.float32)), case["name"]
+    # the offsets cover exactly {-pad .. pad}: nine values for the reference's padding = 4
+    dx, dy, _ = ref.decisions(np.arange(5000), fx["seed"], fx["stream"], 0, 4, True)
+    assert sorted(set(dx.tolist())) == list(range(-4, 5)) and sorted(set(dy.tolist())) == list(range(-4, 5))
+
+
+@pytest.mark.gpu
+def test_kernel_reproduces_the_hand_computed_crop_and_flip_fixture():
+    fx = _semantics_fixture()
+    data = torch.tensor(fx["images"], dtype=torch.float32)[:, None].cuda()
+    aug = augment.RandomCropFlip(pad=fx["pad"], flip=True, seed=fx["seed"], stream=fx["stream"])
+    for case in fx["cases"]:
+        got = aug.gather(data, torch.tensor([case["row"]]).cuda(), case["draw"]).cpu().numpy()
+        assert np.array_equal(got[0, 0], np.asarray(case["out"], dtype=np.float32)), case["name"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,pad,flip", [((500, 3, 32, 32), 4, True), ((64, 1, 28, 28), 2, False),
                                             ((9, 5, 6, 10), 0, True), ((9, 2, 7, 5), 3, True)])

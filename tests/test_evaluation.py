@@ -199,3 +199,55 @@ def test_resident_copy_of_a_host_test_set_follows_the_loader_object_and_its_data
     finally:
         torch.Tensor.to = real_to
         ev._resident_cache.clear()
+
+
+# ---- an independent pin (round 6): the tables against a float64 plain-torch evaluation of the ORACLE's nets -----------
+def _oracle_tables(name, samples, x, y, E):
+    """lps [E, N], acc [E, N, C] in float64 from oracle/nets.py's restatement of the network (torch.nn.functional layers,
+    evaluation-mode BatchNorm) loaded with the same state dicts -- statement by statement what exp_utils.py:250-283 does:
+    load sample e, preds = model(x), lps[e] = preds.log_prob(y), acc[e] = preds.logits (normalised)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import nets as oracle_nets
+    net = oracle_nets.BUILDERS[name](weight_prior="gaussian").double().eval()
+    lps, acc = [], []
+    for e in range(E):
+        state = {k.replace("net.module.", "net."): v[e].detach().cpu().to(torch.float64 if v.is_floating_point() else v.dtype)
+                 for k, v in samples.items()}
+        net.load_state_dict(state)
+        with torch.no_grad():
+            preds = net(x.double())
+        lps.append(preds.log_prob(y))
+        acc.append(preds.logits)
+    return torch.stack(lps), torch.stack(acc)
+
+
+def _check_against_oracle(name, device):
+    net, loader, samples, y = _setup(name, n=96, E=3, device=device)
+    x = torch.cat([bx for bx, _ in loader]).cpu()
+    lps, acc, labels, kind = ev.predictive_tables(net, loader, samples)
+    want_lps, want_acc = _oracle_tables(name, samples, x, y, 3)
+    assert kind == "cat" and torch.equal(labels.cpu(), y)
+    torch.testing.assert_close(lps.cpu(), want_lps, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(acc.cpu(), want_acc, rtol=1e-5, atol=1e-5)
+    # ... and the ensemble numbers the runner logs, from the oracle's tables by the reference's formula (exp_utils.py:300-321)
+    got = ev.evaluate_model(net, loader, samples)
+    lp_ens = (want_lps.logsumexp(0) - np.log(3)).mean().item()
+    ens = want_acc.logsumexp(0) - np.log(3)
+    assert got["lp_ensemble"] == pytest.approx(lp_ens, rel=1e-5, abs=1e-5)
+    assert got["lp_last"] == pytest.approx(want_lps[-1].mean().item(), rel=1e-5, abs=1e-5)
+    assert got["acc_ensemble"] == pytest.approx(ens.argmax(-1).eq(y).double().mean().item(), abs=1e-9)
+    assert got["acc_last"] == pytest.approx(want_acc[-1].argmax(-1).eq(y).double().mean().item(), abs=1e-9)
+
+
+@pytest.mark.parametrize("name", ["classificationdensenet", "classificationconvnet", "googleresnet"])
+def test_tables_match_a_float64_evaluation_of_the_oracle_nets_cpu(name):
+    _check_against_oracle(name, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["classificationdensenet", "classificationconvnet", "googleresnet"])
+def test_tables_match_a_float64_evaluation_of_the_oracle_nets_gpu(name):
+    "the HIP evaluation path (captured forwards, conv + BatchNorm-eval epilogue kernels) against the same oracle tables"
+    _check_against_oracle(name, "cuda:0")
