@@ -487,10 +487,11 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30, cycles=
     batches = [b for b in pool if len(b[0]) == 128]
     from bnn_priors_amd import multichain
     runners, streams, steps_of = [], [], []
-    picked = multichain.concurrent_streams(max(ks), device)        # streams that do not share a hardware queue
+    # streams that do not share a hardware queue, at most multichain.MAX_CHAIN_STREAMS of them (chains beyond that share)
+    picked = multichain.chain_streams(max(ks), device)
     multichain.reserve(picked, device)                             # (the chains' exact passes take their lanes from the rest)
     for c in range(max(ks)):
-        st = picked[c % len(picked)]
+        st = picked[c]
         with torch.cuda.stream(st):
             model = make_model(args.workload, device, args.weight_prior)
             loader = torch.utils.data.DataLoader(_SyntheticSet(N), batch_size=128, shuffle=True)
@@ -562,7 +563,8 @@ def chains_per_gpu_streams(args, device, rank, ks, steps=200, warmup=30, cycles=
                 cycle()
             torch.cuda.synchronize(device)
             out[str(K)]["aggregate_samples_per_s"] = round(K * cycles / (time.perf_counter() - ts), 3)
-    out["distinct_hw_queues"] = len(picked)
+    out["distinct_hw_queues"] = len({st.cuda_stream for st in picked})
+    out["max_chain_streams"] = multichain.MAX_CHAIN_STREAMS
     return out
 
 
@@ -1264,7 +1266,8 @@ def main():
                 out["chains_per_gpu"] = dict(
                     chains_per_gpu_streams(args, device, rank, [int(k) for k in stream_chains.split(",")],
                                            cycles=2 if args.samples >= 10 else 0),
-                    method="K runners, each with its own captured step on its own HIP stream (no augmentation gather)")
+                    method="K runners with their own captured steps on min(K, 4) HIP streams that own a hardware queue each "
+                           "(chain c on stream c mod 4; no augmentation gather)")
             except Exception as exc:       # an extension after the timed region: never takes the bench line down
                 out["chains_per_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
         other = args.other_workloads

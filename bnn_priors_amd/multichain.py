@@ -30,6 +30,13 @@ _distinct = {}      # device index -> streams measured to own a hardware queue e
 _probes = {}        # device index -> how often the measurement ran (a busy GPU makes it reject good streams: it is repeated)
 _reserved = {}      # device index -> handles of the streams that carry a chain's own launches (never handed out as lanes)
 MAX_PROBES = 3
+# How many streams carry CHAINS at once.  The spin-kernel race finds up to 8 queues that run trivial kernels side by side,
+# but with real work the aggregate of K chains on K streams collapses beyond four (googleresnet, round 6,
+# profiles/r06_chains_per_gpu.txt: lock-step of 4 chains 1.93 ms, of 5 chains 3.35 ms, of 8 chains 4.93 ms; the same with
+# GPU_MAX_HW_QUEUES=16) -- four queues make progress together, a fifth makes the hardware take turns.  More chains than this
+# share the four streams (two chains on one stream run back to back, which costs nothing against taking turns): 8 chains
+# then run at the aggregate of 4 instead of 0.79 of it.
+MAX_CHAIN_STREAMS = 4
 
 
 def _measure(device, candidates, cycles, links):
@@ -116,6 +123,12 @@ def lanes(k, device, exclude=()):
     return out
 
 
+def chain_streams(k, device):
+    "one stream per chain for ``k`` chains: at most MAX_CHAIN_STREAMS distinct ones, dealt round-robin (chain c on stream c mod 4)"
+    own = concurrent_streams(min(k, MAX_CHAIN_STREAMS), device) or [torch.cuda.Stream(device=device)]
+    return spread(own, k)
+
+
 def spread(streams, n):
     "``n`` streams out of ``streams``, cycling when there are fewer (work on a shared stream simply runs back to back)"
     return [streams[i % len(streams)] for i in range(n)]
@@ -129,7 +142,7 @@ def run_on_streams(runners, streams=None):
         return
     device = next(runners[0].model.parameters()).device
     if streams is None:
-        streams = spread(concurrent_streams(len(runners), device) or [torch.cuda.Stream(device=device)], len(runners))
+        streams = chain_streams(len(runners), device)
     reserve(streams, device)        # (the chains' exact passes take their lanes from the rest)
     main = torch.cuda.current_stream(device)
     for s in streams:
