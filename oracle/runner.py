@@ -95,7 +95,20 @@ def time_cpu_baseline(make_model, batches, *, num_data, lr, momentum, temperatur
             cpu_leapfrog(model, opt, sched, x, y, step, num_data)
         n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, 1.0, 3)
         calib[t] = n / dt
-    best = max(calib, key=calib.get)
+    # the one-second figures of neighbouring thread counts are within each other's noise (8 vs 16 threads differed by 5 % in
+    # calibration and by 30 % over 30 s in round 6): the two best candidates are timed again, three seconds each, and the
+    # winner of THAT comparison runs the sample -- the baseline must not be handicapped by a lucky second
+    finalists = sorted(calib, key=calib.get, reverse=True)[:2]
+    if len(finalists) == 2:
+        again = {}
+        for t in finalists:
+            torch.set_num_threads(t)
+            n, dt, step = _timed_loop(model, opt, sched, batches, num_data, step, 3.0, 3)
+            again[t] = n / dt
+            calib[f"{t} (3 s)"] = n / dt
+        best = max(again, key=again.get)
+    else:
+        best = finalists[0]
     torch.set_num_threads(best)
     for _ in range(warmup):
         step += 1
