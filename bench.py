@@ -784,6 +784,12 @@ def step_roofline(rows, ms_per_step):
     belongs to the loaded library (else null)."""
     flops = sum(r["algorithmic_flops_per_launch"] * r["launches_per_step"] for r in rows
                 if r.get("bound") == "mfma" and r.get("launches_per_step"))
+    # + the contractions the table has no row for (googleresnet at 128 images; forward, data gradient, weight gradient):
+    # the 3 -> 16 stem (no data gradient) and the two down-sampling pairs (3x3 / stride 2 + 1x1 shortcut)
+    n = 128
+    stem = 2 * n * 32 * 32 * 3 * 16 * 9 * 2
+    down = sum(2 * n * hw * hw * cin * 2 * cin * (9 + 1) * 3 for cin, hw in ((16, 16), (32, 8)))
+    flops += stem + down
     ach = flops / (ms_per_step * 1e-3) / 1e12
     out = dict(flops_per_step=round(flops), achieved_tflops=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
                frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), launches_per_step=None, gpu_busy_us=None)

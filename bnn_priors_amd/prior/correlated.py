@@ -56,73 +56,82 @@ class ConvCorrNormalGamma(ConvCorrelatedNormal):
         super().__init__(shape, loc, scale=_gamma_scale(scale, rate), lengthscale=_gamma_scale(lengthscale, rate))
 
 
-class _PCATransform(td.Transform):
+class _Whitening(td.Transform):
+    "x -> x A + m on the flattened last two dimensions (A = the covariance's PCA factor); its log-determinant is constant"
     domain = td.constraints.real
     codomain = td.constraints.real
     event_dim = 2
     bijective = True
 
-    def __init__(self, loc, scale, inv_scale, log_det, cache_size=0):
-        super().__init__(cache_size=cache_size)
-        self.loc, self.scale, self.inv_scale, self._log_det = loc, scale, inv_scale, log_det
+    def __init__(self, shift, factor, inverse_factor, log_det):
+        super().__init__(cache_size=0)
+        self.shift, self.factor, self.inverse_factor, self.log_det = shift, factor, inverse_factor, log_det
 
-    def log_abs_det_jacobian(self, x, y):
-        return self._log_det
+    def _flat(self, t):
+        return t.view(t.shape[:-2] + (-1,))
 
     def _call(self, x):
-        flat = x.view(x.shape[:-2] + (-1,))
-        return (flat @ self.scale + self.loc).view(x.shape)
+        return (self._flat(x) @ self.factor + self.shift).view(x.shape)
 
     def _inverse(self, y):
-        flat = y.view(y.shape[:-2] + (-1,))
-        return ((flat - self.loc) @ self.inv_scale).view(y.shape)
+        return ((self._flat(y) - self.shift) @ self.inverse_factor).view(y.shape)
+
+    def log_abs_det_jacobian(self, x, y):
+        return self.log_det
+
+
+def _pca_factors(cov):
+    "(A, A^-1, log det A) with A = diag(sqrt(lambda)) V^T of cov = V diag(lambda) V^T, computed in float64"
+    lam, vec = torch.linalg.eigh(cov.to(torch.float64))
+    root = lam.sqrt()
+    return root.unsqueeze(-1) * vec.t(), vec / root, lam.log().sum().view((1, 1)) / 2
 
 
 class ConvCovariance(Prior):
-    "base of the fixed-covariance priors: the covariance's PCA factors are buffers (``scale``, ``inv_scale``, ``log_sqrt_vals``)"
+    """base of the fixed-covariance priors: an element-wise base density (``_base``) pushed through the whitening
+    transform of a given covariance of the filter positions; the factors are buffers (``scale``, ``inv_scale``,
+    ``log_sqrt_vals``: the reference's names, prior/conv_loc_scale.py:46-70).  A NUMBER as ``cov`` is a standard deviation."""
     fused_kind = None
 
     def __init__(self, shape, loc, cov, **kwargs):
+        n_pos = shape[-2] * shape[-1]
         if isinstance(cov, Number) or len(cov.shape) == 0:
-            cov = torch.eye(shape[-2] * shape[-1]) * cov ** 2          # (a number is a standard deviation)
-            loc = torch.zeros(shape[-2] * shape[-1]) + loc
-        scale, inv_scale, log_sqrt_vals = self._break_down_cov(cov)
+            cov, loc = torch.eye(n_pos) * cov ** 2, torch.zeros(n_pos) + loc
         dt = torch.get_default_dtype()
-        super().__init__(shape, loc=loc, scale=scale.to(dt), inv_scale=inv_scale.to(dt), log_sqrt_vals=log_sqrt_vals.to(dt),
-                         event_shape=shape[-2:], **kwargs)
+        factor, inverse, log_det = (t.to(dt) for t in _pca_factors(cov))
+        super().__init__(shape, loc=loc, scale=factor, inv_scale=inverse, log_sqrt_vals=log_det, event_shape=shape[-2:],
+                         **kwargs)
 
-    @staticmethod
-    def _break_down_cov(cov):
-        vals, vecs = torch.linalg.eigh(cov.to(torch.float64))
-        sqrt_vals = vals.sqrt()
-        return sqrt_vals.unsqueeze(-1) * vecs.t(), vecs / sqrt_vals, vals.log().sum().view((1, 1)) / 2
+    def _base(self, zeros, **extra):
+        raise NotImplementedError
+
+    def _dist(self, loc, scale, inv_scale, log_sqrt_vals, event_shape, **extra):
+        zeros = torch.zeros((), device=loc.device, dtype=loc.dtype).expand(event_shape)
+        return td.TransformedDistribution(self._base(zeros, **extra), _Whitening(loc, scale, inv_scale, log_sqrt_vals))
 
     def assign_cov(self, cov):
-        scale, inv_scale, log_sqrt_vals = self._break_down_cov(cov)
-        self.scale.copy_(scale)
-        self.inv_scale.copy_(inv_scale)
-        self.log_sqrt_vals.copy_(log_sqrt_vals)
+        for buf, new in zip((self.scale, self.inv_scale, self.log_sqrt_vals), _pca_factors(cov)):
+            buf.copy_(new)
 
 
 class FixedCovNormal(ConvCovariance):
     def __init__(self, shape, loc, cov):
         super().__init__(shape, loc, cov)
 
-    def _dist(self, loc, scale, inv_scale, log_sqrt_vals, event_shape):
-        zeros = torch.zeros((), device=loc.device, dtype=loc.dtype).expand(event_shape)
-        return td.TransformedDistribution(td.Normal(zeros, zeros + 1), _PCATransform(loc, scale, inv_scale, log_sqrt_vals))
+    def _base(self, zeros):
+        return td.Normal(zeros, zeros + 1)
 
 
 class FixedCovGenNorm(ConvCovariance):
-    def __init__(self, shape, loc, cov, beta, base_scale=None):
-        if base_scale is None:
-            if isinstance(beta, Number):
-                beta = torch.tensor(beta, dtype=torch.float64)
-            base_scale = (torch.lgamma(1 / beta) - torch.lgamma(3 / beta)).div(2).exp()      # unit variance
-        super().__init__(shape, loc, cov, beta=beta, base_scale=base_scale.to(torch.get_default_dtype()))
+    "(the reference notes that sampling is slightly off -- the CDF's accuracy -- and irrelevant for inference)"
 
-    def _dist(self, loc, scale, inv_scale, log_sqrt_vals, beta, base_scale, event_shape):
-        zeros = torch.zeros((), device=loc.device, dtype=loc.dtype).expand(event_shape)
-        return td.TransformedDistribution(
-            GeneralizedNormal(loc=zeros, scale=base_scale.expand(event_shape), beta=beta.expand(event_shape)),
-            _PCATransform(loc, scale, inv_scale, log_sqrt_vals))
+    def __init__(self, shape, loc, cov, beta, base_scale=None):
+        if isinstance(beta, Number):
+            beta = torch.tensor(beta, dtype=torch.float64)        # (stored in double, as the reference stores it)
+        if base_scale is None:        # the scale that gives the base density unit variance
+            base_scale = ((torch.lgamma(1 / beta) - torch.lgamma(3 / beta)) / 2).exp()
+        super().__init__(shape, loc, cov, beta=beta, base_scale=torch.as_tensor(base_scale).to(torch.get_default_dtype()))
+
+    def _base(self, zeros, beta, base_scale):
+        shape = zeros.shape
+        return GeneralizedNormal(loc=zeros, scale=base_scale.expand(shape), beta=beta.expand(shape))
