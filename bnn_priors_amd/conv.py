@@ -402,7 +402,9 @@ _pending = []
 # joins it again before the reduction, captured into the step's hipGraph as parallel branches.  The dependent chain
 # would carry 10 us data-gradient launches instead of 17 - 22 us merged ones.  On MI355X / ROCm 7.2 every
 # fork + join edge of a replayed graph costs ~19 us of cross-queue signalling: 16 of them per step, googleresnet
-# 1,137 -> 845 steps/s.  The merged launch (both halves' workgroups in one grid) stays the default;
+# 1,137 -> 845 steps/s (round 2; round 6 on the current tree: 1,272 -> 307, and 415 with ONE fork per pass -- a graph with
+# any parallel branch replays 2-3x slower than a chain: profiles/r06_lab_side_queue.txt).  The merged launch (both halves'
+# workgroups in one grid) stays the default;
 # SGMCMC_CONV_SIDE_STREAM=1 enables this route (same workgroups, same bits: tested).
 SIDE_STREAM = os.environ.get("SGMCMC_CONV_SIDE_STREAM", "0") == "1"
 if SIDE_STREAM and not _hip.ALTERNATIVES:

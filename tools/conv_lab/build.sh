@@ -7,3 +7,5 @@ hipcc $F -DNO_STAMPS lab.hip -o lab && hipcc $F lab.hip -o lab_st
 hipcc $F -DNO_STAMPS lab50.hip -o lab50 && hipcc $F lab50.hip -o lab50_st
 hipcc $F atom.hip -o atom
 hipcc $F lab_uni.hip -o lab_uni && hipcc $F -DUNI_STAMPS lab_uni.hip -o lab_uni_st
+hipcc $F lab_pair.hip -o lab_pair
+hipcc $F lab_side.hip -o lab_side
