@@ -25,7 +25,7 @@ def test_supported_is_false_on_cpu_and_in_eval_mode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,c,hw", [(128, 16, 32), (128, 32, 16), (128, 64, 8), (5, 16, 32), (1, 64, 8), (37, 3, 6)])
+@pytest.mark.parametrize("n,c,hw", [(128, 16, 32), (128, 32, 16), (128, 64, 8), (80, 16, 32), (96, 64, 8), (5, 16, 32), (1, 64, 8), (37, 3, 6)])
 @pytest.mark.parametrize("relu,residual", [(True, False), (True, True), (False, False), (False, True)])
 def test_fused_bn_matches_aten(n, c, hw, relu, residual):
     g = torch.Generator().manual_seed(n * 1000 + c)

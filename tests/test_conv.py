@@ -40,7 +40,7 @@ def test_supported_is_false_off_the_table():
 @pytest.mark.gpu
 @pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("c,hw", SHAPES)
-@pytest.mark.parametrize("n", [128, 5, 1])
+@pytest.mark.parametrize("n", [128, 80, 5, 1])
 def test_kernels_match_float64_reference(c, hw, n, persistent, monkeypatch):
     """forward, data gradient, weight gradient: error of the order of MIOpen's own (fp32 summation order) -- for the
     default kernels (csrc/conv_hip.inc) and for the persistent ones on prepared weight fragments (csrc/conv2_hip.inc)"""
@@ -229,7 +229,7 @@ def test_epilogue_statistics_feed_the_batchnorm(c, hw, persistent, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,hwi", sorted(conv.DOWN_SHAPES))
-@pytest.mark.parametrize("n", [128, 7, 1])
+@pytest.mark.parametrize("n", [128, 80, 7, 1])
 def test_down_block_pair_matches_float64_reference(cin, hwi, n):
     "3x3/stride 2 + 1x1/stride 2 on the same input as one operator: outputs, statistics, all three gradients"
     g = torch.Generator().manual_seed(100 * cin + n)
@@ -625,7 +625,7 @@ def test_a_convnet_width_off_the_tables_is_loud_not_silent():
 @ALT
 @pytest.mark.gpu
 @pytest.mark.parametrize("c,hw", [(16, 32), (32, 16)])
-@pytest.mark.parametrize("n", [128, 5, 1])
+@pytest.mark.parametrize("n", [128, 96, 5, 1])
 @pytest.mark.parametrize("epi", ["none", "add_masked+sums", "add+sums+mask_dx"])
 def test_uniform_backward_matches_the_merged_launch(c, hw, n, epi):
     """round 6's uniform backward convolution (csrc/conv_uni_hip.inc, a measured alternative): dx and the BatchNorm
